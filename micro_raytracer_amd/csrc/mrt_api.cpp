@@ -1,0 +1,399 @@
+// mrt_api.cpp — the C ABI of include/mrt.h: context management, uploads, launches, read-back.
+// Replaces the reference's Sampler (src/sampler.rs:11-100); there is no CPU rendering path here:
+// without a HIP device every entry point that needs one fails with MRT_ERR_DEVICE.
+#include <hip/hip_runtime_api.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/mrt.h"
+#include "mrt_kernels.h"
+#include "mrt_pack.h"
+
+using namespace mrt;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_status = MRT_OK;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    g_status = code;
+    return code;
+}
+void ok() { g_status = MRT_OK; }
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(MRT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+constexpr size_t kLdsLimit = 160u * 1024u;          // LDS per CU on gfx950
+constexpr size_t kTwoCopies = 78u * 1024u;          // <= this: two workgroups (two LDS copies) per CU
+
+}  // namespace
+
+struct mrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Packed pk;
+    Params P;
+    u32 *d_blob = nullptr;
+    float *d_accum = nullptr;            // [local_rows][nw][3]
+    unsigned long long *d_segments = nullptr;
+    u32 count = 0;                       // Sampler.last_count
+    uint64_t seed = 0;
+    u32 shard_index = 0, shard_count = 1, shard_rows = 8, local_rows = 0;
+    std::vector<u32> row_of;             // local row -> frame row
+    bool whole_frame = true;             // accumulator holds every row (shard_count == 1 or after set_accum)
+    float *d_full = nullptr;             // [nh][nw][3] when a sharded context received a full frame
+    u32 full_count = 0;
+    u32 block_threads = 256;
+    bool scene_in_lds = true;
+    // img resources (lazy)
+    unsigned char *d_ss = nullptr, *d_out = nullptr;
+    float *d_tmp = nullptr;
+    u32 *d_vl = nullptr, *d_vc = nullptr, *d_hl = nullptr, *d_hc = nullptr;
+    float *d_vw = nullptr, *d_hw = nullptr;
+    u32 vcap = 0, hcap = 0;
+    mrt_stats stats;
+};
+
+namespace {
+
+int set_device(const mrt_ctx *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return MRT_OK;
+}
+
+void free_ctx(mrt_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void *ptrs[] = {c->d_blob, c->d_accum, c->d_segments, c->d_full, c->d_ss, c->d_out, c->d_tmp, c->d_vl, c->d_vc, c->d_hl, c->d_hc, c->d_vw, c->d_hw};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t mrt_abi_version(void) { return MRT_ABI_VERSION; }
+const char *mrt_last_error(void) { return g_err.c_str(); }
+int mrt_last_status(void) { return g_status; }
+
+int mrt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
+{
+    g_err.clear();
+    if (!desc || !opts) { fail(MRT_ERR_ARG, "mrt_create: null argument"); return nullptr; }
+    if (opts->abi_version != MRT_ABI_VERSION) { fail(MRT_ERR_ARG, "mrt_create: ABI version %u, library has %u", opts->abi_version, MRT_ABI_VERSION); return nullptr; }
+    if (opts->n_devices > 1) { fail(MRT_ERR_ARG, "mrt_create: in-process multi-device contexts are not available in this build; use one context per device with shard_index/shard_count"); return nullptr; }
+    const u32 shard_count = opts->shard_count ? opts->shard_count : 1;
+    if (opts->shard_index >= shard_count) { fail(MRT_ERR_ARG, "mrt_create: shard_index %u >= shard_count %u", opts->shard_index, shard_count); return nullptr; }
+
+    mrt_ctx *c = new mrt_ctx();
+    std::string err;
+    const int rc = pack_scene(desc, c->pk, err);
+    if (rc != MRT_OK) { fail(rc, "mrt_create: %s", err.c_str()); delete c; return nullptr; }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fail(MRT_ERR_DEVICE, "mrt_create: no HIP device (this backend has no CPU path)");
+        delete c; return nullptr;
+    }
+    int dev = opts->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { fail(MRT_ERR_ARG, "mrt_create: device %d of %d", dev, ndev); delete c; return nullptr; }
+    c->device = dev;
+    c->seed = opts->seed;
+    c->shard_index = opts->shard_index; c->shard_count = shard_count;
+    c->shard_rows = opts->shard_rows ? opts->shard_rows : 8;
+    c->whole_frame = shard_count == 1;
+
+    // rows of this shard: row block b (shard_rows rows) belongs to shard b % shard_count
+    const u32 nh = c->pk.nh, nw = c->pk.nw;
+    for (u32 y = 0; y < nh; ++y) if ((y / c->shard_rows) % shard_count == c->shard_index) c->row_of.push_back(y);
+    c->local_rows = (u32)c->row_of.size();
+
+    auto bail = [&](int code, const char *what, hipError_t e) { fail(code, "mrt_create: %s: %s", what, hipGetErrorString(e)); free_ctx(c); return (mrt_ctx *)nullptr; };
+    hipError_t e;
+    if ((e = hipSetDevice(dev)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
+    const size_t blob_bytes = (size_t)c->pk.blob.size() * 4;
+    if ((e = hipMalloc((void **)&c->d_blob, blob_bytes ? blob_bytes : 16)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
+    if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), blob_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
+    const size_t acc_bytes = (size_t)(c->local_rows ? c->local_rows : 1) * nw * 3 * sizeof(float);
+    if ((e = hipMalloc((void **)&c->d_accum, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(accumulator)", e);
+    if ((e = hipMemset(c->d_accum, 0, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
+    if ((e = hipMalloc((void **)&c->d_segments, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);
+    if ((e = hipMemset(c->d_segments, 0, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
+
+    // launch shape: two 256-thread workgroups (2x2 wave tiles of 8x8 pixels) per CU while two LDS copies of the
+    // scene fit; beyond that one 512-thread workgroup (4x2 wave tiles) shares a single copy; scenes larger than
+    // the LDS are read through L2 instead.
+    c->scene_in_lds = blob_bytes + 1024 <= kLdsLimit;
+    if (blob_bytes <= kTwoCopies || !c->scene_in_lds) { c->block_threads = 256; c->pk.P.tiles_x = 2; c->pk.P.tiles_y = 2; }
+    else { c->block_threads = 512; c->pk.P.tiles_x = 4; c->pk.P.tiles_y = 2; }
+    if (c->scene_in_lds && (e = configure_pt(kLdsLimit)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipFuncSetAttribute", e);
+
+    c->P = c->pk.P;
+    c->P.local_rows = c->local_rows; c->P.shard_index = c->shard_index; c->P.shard_count = c->shard_count; c->P.shard_rows = c->shard_rows;
+    c->P.seed_lo = (u32)c->seed; c->P.seed_hi = (u32)(c->seed >> 32);
+    c->P.blob = c->d_blob; c->P.accum = c->d_accum; c->P.segments = c->d_segments;
+    c->P.count_segments = 1;
+    memset(&c->stats, 0, sizeof c->stats);
+    c->stats.lds_bytes = c->scene_in_lds ? (u32)blob_bytes : 0;
+    c->stats.block_threads = c->block_threads;
+    c->stats.scene_bytes = (u32)blob_bytes;
+    ok();
+    return c;
+}
+
+void mrt_destroy(mrt_ctx *ctx) { free_ctx(ctx); }
+
+int mrt_execute(mrt_ctx *c, uint32_t n_samples, double *seconds)
+{
+    if (!c) return fail(MRT_ERR_ARG, "mrt_execute: null context");
+    if ((unsigned long long)c->count + n_samples > 0xffffffffull) return fail(MRT_ERR_LIMIT, "mrt_execute: sample count overflows u32");
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = set_device(c);
+    if (rc) return rc;
+    c->stats.kernel_ms = 0; c->stats.gather_ms = 0; c->stats.launches = 0; c->stats.samples = 0; c->stats.segments = 0;
+    if (n_samples && c->local_rows) {
+        HIP_TRY(hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
+        c->P.n_samples = n_samples;
+        c->P.sample_base = c->count;
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->stream));
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        unsigned long long seg = 0;
+        HIP_TRY(hipMemcpy(&seg, c->d_segments, sizeof seg, hipMemcpyDeviceToHost));
+        c->stats.kernel_ms = ms; c->stats.launches = 1; c->stats.segments = seg;
+        c->stats.samples = (uint64_t)c->local_rows * c->pk.nw * n_samples;
+    }
+    c->count += n_samples;                                        // src/sampler.rs:76
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ok();
+    return MRT_OK;
+}
+
+int mrt_dims(const mrt_ctx *c, uint32_t *nw, uint32_t *nh, uint32_t *local_rows)
+{
+    if (!c) return fail(MRT_ERR_ARG, "mrt_dims: null context");
+    if (nw) *nw = c->pk.nw;
+    if (nh) *nh = c->pk.nh;
+    if (local_rows) *local_rows = c->local_rows;
+    ok();
+    return MRT_OK;
+}
+
+int mrt_accum_local(mrt_ctx *c, float *rgb, uint32_t *rows)
+{
+    if (!c) return fail(MRT_ERR_ARG, "mrt_accum_local: null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (rows) memcpy(rows, c->row_of.data(), sizeof(u32) * c->local_rows);
+    if (rgb && c->local_rows) HIP_TRY(hipMemcpy(rgb, c->d_accum, (size_t)c->local_rows * c->pk.nw * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    ok();
+    return MRT_OK;
+}
+
+int mrt_accum(mrt_ctx *c, float *rgb, uint32_t *count)
+{
+    if (!c) return fail(MRT_ERR_ARG, "mrt_accum: null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)c->pk.nw * 3 * sizeof(float);
+    if (rgb) {
+        if (c->d_full) {
+            HIP_TRY(hipMemcpy(rgb, c->d_full, row_bytes * c->pk.nh, hipMemcpyDeviceToHost));
+        } else if (c->shard_count == 1) {
+            HIP_TRY(hipMemcpy(rgb, c->d_accum, row_bytes * c->pk.nh, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> tmp((size_t)c->local_rows * c->pk.nw * 3);
+            if (c->local_rows) HIP_TRY(hipMemcpy(tmp.data(), c->d_accum, row_bytes * c->local_rows, hipMemcpyDeviceToHost));
+            for (u32 r = 0; r < c->local_rows; ++r) memcpy((char *)rgb + row_bytes * c->row_of[r], (char *)tmp.data() + row_bytes * r, row_bytes);
+        }
+    }
+    if (count) *count = c->d_full ? c->full_count : c->count;
+    ok();
+    return MRT_OK;
+}
+
+int mrt_accum_device_ptr(mrt_ctx *c, void **dev_ptr, size_t *bytes)
+{
+    if (!c) return fail(MRT_ERR_ARG, "mrt_accum_device_ptr: null context");
+    if (dev_ptr) *dev_ptr = c->d_accum;
+    if (bytes) *bytes = (size_t)c->local_rows * c->pk.nw * 3 * sizeof(float);
+    ok();
+    return MRT_OK;
+}
+
+int mrt_set_accum(mrt_ctx *c, const float *rgb, uint32_t count)
+{
+    if (!c || !rgb) return fail(MRT_ERR_ARG, "mrt_set_accum: null argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)c->pk.nw * 3 * sizeof(float);
+    if (c->shard_count == 1) {
+        HIP_TRY(hipMemcpy(c->d_accum, rgb, row_bytes * c->pk.nh, hipMemcpyHostToDevice));
+        c->count = count;
+    } else {
+        // a sharded context keeps the gathered frame next to its own rows (it is only read by mrt_img / mrt_accum)
+        if (!c->d_full) HIP_TRY(hipMalloc((void **)&c->d_full, row_bytes * c->pk.nh));
+        HIP_TRY(hipMemcpy(c->d_full, rgb, row_bytes * c->pk.nh, hipMemcpyHostToDevice));
+        c->full_count = count;
+    }
+    ok();
+    return MRT_OK;
+}
+
+int mrt_reset(mrt_ctx *c)
+{
+    if (!c) return fail(MRT_ERR_ARG, "mrt_reset: null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(c->d_accum, 0, (size_t)(c->local_rows ? c->local_rows : 1) * c->pk.nw * 3 * sizeof(float)));
+    if (c->d_full) { (void)hipFree(c->d_full); c->d_full = nullptr; }
+    c->count = 0; c->full_count = 0;
+    ok();
+    return MRT_OK;
+}
+
+static int img_prepare(mrt_ctx *c)
+{
+    const u32 nw = c->pk.nw, nh = c->pk.nh, rw = c->pk.res_w, rh = c->pk.res_h;
+    if (!c->d_ss) HIP_TRY(hipMalloc((void **)&c->d_ss, (size_t)nw * nh * 3));
+    if (rw == nw && rh == nh) return MRT_OK;
+    if (rw == 0 || rh == 0) return fail(MRT_ERR_SCENE, "mrt_img: zero output resolution");
+    if (!c->d_out) {
+        ResampleTaps v, h;
+        lanczos3_taps(nh, rh, v);
+        lanczos3_taps(nw, rw, h);
+        c->vcap = v.cap; c->hcap = h.cap;
+        HIP_TRY(hipMalloc((void **)&c->d_vl, sizeof(u32) * rh));
+        HIP_TRY(hipMalloc((void **)&c->d_vc, sizeof(u32) * rh));
+        HIP_TRY(hipMalloc((void **)&c->d_vw, sizeof(float) * (size_t)rh * v.cap));
+        HIP_TRY(hipMalloc((void **)&c->d_hl, sizeof(u32) * rw));
+        HIP_TRY(hipMalloc((void **)&c->d_hc, sizeof(u32) * rw));
+        HIP_TRY(hipMalloc((void **)&c->d_hw, sizeof(float) * (size_t)rw * h.cap));
+        HIP_TRY(hipMemcpy(c->d_vl, v.left.data(), sizeof(u32) * rh, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_vc, v.count.data(), sizeof(u32) * rh, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_vw, v.weight.data(), sizeof(float) * (size_t)rh * v.cap, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_hl, h.left.data(), sizeof(u32) * rw, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_hc, h.count.data(), sizeof(u32) * rw, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_hw, h.weight.data(), sizeof(float) * (size_t)rw * h.cap, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&c->d_tmp, sizeof(float) * (size_t)nw * rh * 3));
+        HIP_TRY(hipMalloc((void **)&c->d_out, (size_t)rw * rh * 3));
+    }
+    return MRT_OK;
+}
+
+static int img_tonemap(mrt_ctx *c)
+{
+    const float *src = c->d_full ? c->d_full : c->d_accum;
+    const u32 count = c->d_full ? c->full_count : c->count;
+    if (!c->d_full && c->shard_count != 1) return fail(MRT_ERR_STATE, "mrt_img: this context holds only its own rows; gather and mrt_set_accum first");
+    if (count == 0) return fail(MRT_ERR_STATE, "mrt_img: no samples accumulated (the reference would panic on an empty map, src/sampler.rs:85)");
+    const float rc = 1.0f / (float)count;
+    const float wexp = (1.0f - c->pk.exp) * (1.0f - c->pk.exp);
+    HIP_TRY(launch_tonemap(src, c->d_ss, c->pk.nw * c->pk.nh, rc, c->pk.gamma, wexp, c->stream));
+    return MRT_OK;
+}
+
+int mrt_img_ss(mrt_ctx *c, uint8_t *rgb8)
+{
+    if (!c || !rgb8) return fail(MRT_ERR_ARG, "mrt_img_ss: null argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = img_prepare(c))) return rc;
+    if ((rc = img_tonemap(c))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(rgb8, c->d_ss, (size_t)c->pk.nw * c->pk.nh * 3, hipMemcpyDeviceToHost));
+    ok();
+    return MRT_OK;
+}
+
+int mrt_img(mrt_ctx *c, uint8_t *rgb8)
+{
+    if (!c || !rgb8) return fail(MRT_ERR_ARG, "mrt_img: null argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = img_prepare(c))) return rc;
+    if ((rc = img_tonemap(c))) return rc;
+    const u32 nw = c->pk.nw, nh = c->pk.nh, rw = c->pk.res_w, rh = c->pk.res_h;
+    if (rw == nw && rh == nh) {    // image 0.24 resize copies when the dimensions match
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(rgb8, c->d_ss, (size_t)nw * nh * 3, hipMemcpyDeviceToHost));
+        ok();
+        return MRT_OK;
+    }
+    HIP_TRY(launch_lanczos_v(c->d_ss, c->d_tmp, nw, rh, c->d_vl, c->d_vc, c->d_vw, c->vcap, c->stream));
+    HIP_TRY(launch_lanczos_h(c->d_tmp, c->d_out, nw, rw, rh, c->d_hl, c->d_hc, c->d_hw, c->hcap, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(rgb8, c->d_out, (size_t)rw * rh * 3, hipMemcpyDeviceToHost));
+    ok();
+    return MRT_OK;
+}
+
+int mrt_get_stats(const mrt_ctx *c, mrt_stats *out)
+{
+    if (!c || !out) return fail(MRT_ERR_ARG, "mrt_get_stats: null argument");
+    *out = c->stats;
+    ok();
+    return MRT_OK;
+}
+
+int mrt_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n)
+{
+    if (!a || !out) return fail(MRT_ERR_ARG, "mrt_selftest_math: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MRT_ERR_DEVICE, "mrt_selftest_math: no HIP device");
+    if (device < 0) device = 0;
+    HIP_TRY(hipSetDevice(device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    const size_t bytes = n * sizeof(float);
+    if (n == 0) { ok(); return MRT_OK; }
+    HIP_TRY(hipMalloc((void **)&da, bytes));
+    HIP_TRY(hipMalloc((void **)&dout, bytes));
+    HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    if (b) { HIP_TRY(hipMalloc((void **)&db, bytes)); HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
+    HIP_TRY(launch_math_selftest(op, da, db, dout, n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    ok();
+    return MRT_OK;
+}
+
+}  // extern "C"

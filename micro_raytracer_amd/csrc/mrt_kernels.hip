@@ -1,0 +1,183 @@
+// mrt_kernels.hip — gfx950 kernels of libmrt_hip.so.
+//
+//   pt_megakernel    Sampler::execute (reference src/sampler.rs:28-78) and everything of src/rt.rs
+//                    it reaches: one lane per supersampled pixel, all samples of the launch in
+//                    registers, scene staged in LDS, one accumulator read-modify-write per launch.
+//   tonemap_u8       Sampler::img's per-pixel map (src/sampler.rs:84-96)
+//   lanczos3_v/_h    image::imageops::resize(.., Lanczos3) (src/sampler.rs:98): vertical pass to f32,
+//                    horizontal pass to u8, taps precomputed on the host.
+//   math_selftest    elementwise device math contract, for the parity tests.
+//
+// Build: hipcc --offload-arch=gfx950 -ffp-contract=off (no fast-math; IEEE divide / sqrt).
+#include <hip/hip_runtime.h>
+
+#include "mrt_kernels.h"
+#include "mrt_post.h"
+#include "mrt_trace.h"
+
+namespace mrt {
+
+// Workgroup = tiles_x x tiles_y wavefronts, each wavefront an 8x8 pixel tile (64 lanes): neighbouring
+// pixels share most of their path prefix, which keeps the per-lane predicates of the uniform traversal
+// loop coherent.  Rows are the shard-local rows of this context (block-cyclic over shards).
+template <bool SCENE_IN_LDS, int BLOCK_THREADS>
+__global__ void __launch_bounds__(BLOCK_THREADS) pt_megakernel(const Params P)
+{
+    extern __shared__ uint4 lds_blob[];
+    const float *F;
+    if (SCENE_IN_LDS) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(P.blob);
+        const u32 n4 = P.blob_words >> 2;
+        for (u32 i = threadIdx.x; i < n4; i += blockDim.x) lds_blob[i] = g[i];
+        __syncthreads();
+        F = reinterpret_cast<const float *>(lds_blob);
+    } else {
+        F = reinterpret_cast<const float *>(P.blob);
+    }
+
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 wx = wave % P.tiles_x, wy = wave / P.tiles_x;
+    const u32 x = (blockIdx.x * P.tiles_x + wx) * 8u + (lane & 7u);
+    const u32 ry = (blockIdx.y * P.tiles_y + wy) * 8u + (lane >> 3);
+    // shard-local row -> frame row: row block b of this shard is frame row block b * shard_count + shard_index
+    const u32 blk = ry / P.shard_rows;
+    const u32 y = (blk * P.shard_count + P.shard_index) * P.shard_rows + (ry - blk * P.shard_rows);
+    const bool active = x < P.nw && ry < P.local_rows && y < P.nh;
+
+    u32 segments = 0;
+    if (active) {
+        Scn S;
+        S.F = F;
+        S.P = &P;
+        float *px = P.accum + ((size_t)ry * P.nw + x) * 3u;
+        V3 acc = v3(px[0], px[1], px[2]);
+        render_pixel(S, x, y, acc, segments);
+        px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
+    }
+    if (P.count_segments) {
+        // wave-level sum (every lane of the wavefront is here), one atomic per wavefront
+        u32 v = segments;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && v) atomicAdd(P.segments, (unsigned long long)v);
+    }
+}
+
+__global__ void __launch_bounds__(256) tonemap_u8(const float *__restrict__ accum, unsigned char *__restrict__ out,
+                                                  u32 n_px, float rc, float gamma, float wexp)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[(size_t)i * 3 + k] = tonemap_channel(accum[(size_t)i * 3 + k], rc, gamma, wexp);
+}
+
+// vertical_sample of image 0.24: out[oy][x][c] = sum_i src[left+i][x][c] * w[i], f32, taps in order
+__global__ void __launch_bounds__(256) lanczos3_v(const unsigned char *__restrict__ src, float *__restrict__ dst, u32 sw, u32 dh,
+                                                  const u32 *__restrict__ left, const u32 *__restrict__ count,
+                                                  const float *__restrict__ weight, u32 cap)
+{
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;      // element = x * 3 + c
+    const u32 oy = blockIdx.y;
+    if (e >= sw * 3u || oy >= dh) return;
+    const u32 l = left[oy], n = count[oy];
+    const float *w = weight + (size_t)oy * cap;
+    float t = 0.0f;
+    for (u32 i = 0; i < n; ++i) t += (float)src[(size_t)(l + i) * sw * 3u + e] * w[i];
+    dst[(size_t)oy * sw * 3u + e] = t;
+}
+
+// horizontal_sample: clamp to [0,255], round half away from zero, u8
+__global__ void __launch_bounds__(256) lanczos3_h(const float *__restrict__ src, unsigned char *__restrict__ dst, u32 sw, u32 dw, u32 dh,
+                                                  const u32 *__restrict__ left, const u32 *__restrict__ count,
+                                                  const float *__restrict__ weight, u32 cap)
+{
+    const u32 ox = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 y = blockIdx.y;
+    if (ox >= dw || y >= dh) return;
+    const u32 l = left[ox], n = count[ox];
+    const float *w = weight + (size_t)ox * cap;
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    for (u32 i = 0; i < n; ++i) {
+        const float *p = src + ((size_t)y * sw + (l + i)) * 3u;
+        t0 += p[0] * w[i]; t1 += p[1] * w[i]; t2 += p[2] * w[i];
+    }
+    unsigned char *q = dst + ((size_t)y * dw + ox) * 3u;
+    q[0] = resample_to_u8(t0); q[1] = resample_to_u8(t1); q[2] = resample_to_u8(t2);
+}
+
+__global__ void math_selftest(int op, const float *a, const float *b, float *out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b ? b[i] : 0.0f;
+    float s, c, r = 0.0f;
+    switch (op) {
+    case 0: sincos_(x, s, c); r = s; break;
+    case 1: sincos_(x, s, c); r = c; break;
+    case 2: r = acos_(x); break;
+    case 3: r = atan2_(x, y); break;
+    case 4: r = pow_(x, y); break;
+    case 5: r = 1.0f / x; break;
+    case 6: r = sqrt_(x); break;
+    case 7: r = x / y; break;
+    case 8: r = fmax_(x, y); break;
+    case 9: r = fmin_(x, y); break;
+    case 10: r = u2f((u32)total_key(x)); break;
+    case 11: r = u32_to_unit(draw_u32(f2u(x), f2u(y))); break;
+    case 12: r = norm(v3(x, y, 0.25f)).x; break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+// ---- launchers (declared in mrt_kernels.h) ----
+hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, hipStream_t stream)
+{
+    if (block_threads != P.tiles_x * P.tiles_y * 64u || (block_threads != 256u && block_threads != 512u)) return hipErrorInvalidConfiguration;
+    const u32 tile_w = P.tiles_x * 8u, tile_h = P.tiles_y * 8u;
+    dim3 grid((P.nw + tile_w - 1) / tile_w, (P.local_rows + tile_h - 1) / tile_h);
+    const size_t lds = scene_in_lds ? (size_t)P.blob_words * 4u : 0;
+    if (scene_in_lds) {
+        if (block_threads == 256u) hipLaunchKernelGGL((pt_megakernel<true, 256>), grid, dim3(256), lds, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<true, 512>), grid, dim3(512), lds, stream, P);
+    } else {
+        if (block_threads == 256u) hipLaunchKernelGGL((pt_megakernel<false, 256>), grid, dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<false, 512>), grid, dim3(512), 0, stream, P);
+    }
+    return hipGetLastError();
+}
+
+hipError_t configure_pt(size_t max_lds_bytes)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+}
+
+hipError_t launch_tonemap(const float *accum, unsigned char *out, u32 n_px, float rc, float gamma, float wexp, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tonemap_u8, dim3((n_px + 255) / 256), dim3(256), 0, stream, accum, out, n_px, rc, gamma, wexp);
+    return hipGetLastError();
+}
+
+hipError_t launch_lanczos_v(const unsigned char *src, float *dst, u32 sw, u32 dh, const u32 *left, const u32 *count,
+                            const float *weight, u32 cap, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lanczos3_v, dim3((sw * 3u + 255) / 256, dh), dim3(256), 0, stream, src, dst, sw, dh, left, count, weight, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_lanczos_h(const float *src, unsigned char *dst, u32 sw, u32 dw, u32 dh, const u32 *left, const u32 *count,
+                            const float *weight, u32 cap, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lanczos3_h, dim3((dw + 255) / 256, dh), dim3(256), 0, stream, src, dst, sw, dw, dh, left, count, weight, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_math_selftest(int op, const float *a, const float *b, float *out, size_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(math_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace mrt

@@ -1,0 +1,441 @@
+// mrt_pack.cpp — see mrt_pack.h.  Host code only; compiled with -ffp-contract=off so that the
+// hoisted f32 values are the ones the reference would recompute per call.
+#include "mrt_pack.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <array>
+
+namespace mrt {
+namespace {
+
+struct H3 { float x, y, z; };
+inline H3 h3(float x, float y, float z) { H3 r = {x, y, z}; return r; }
+inline H3 hadd(H3 a, H3 b) { return h3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline H3 hsub(H3 a, H3 b) { return h3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline H3 hmuls(H3 a, float s) { return h3(a.x * s, a.y * s, a.z * s); }
+inline H3 hneg(H3 a) { return h3(-a.x, -a.y, -a.z); }
+inline H3 hhadam(H3 a, H3 b) { return h3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline float hdot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline H3 hcross(H3 a, H3 b) { return h3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline float hmag(H3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline H3 hnorm(H3 a) { return hmuls(a, 1.0f / hmag(a)); }
+
+// Mat3f::rotate_y(dir), src/lin.rs:175-183 (only dir.w is used)
+void rotate_y(float w, float *m)
+{
+    const float cw = sqrtf(1.0f - w * w);
+    const float r[9] = {cw, 0.0f, w, 0.0f, 1.0f, 0.0f, -w, 0.0f, cw};
+    memcpy(m, r, sizeof r);
+}
+// Mat4f::lookat(dir, up = (0,0,1)) upper-left 3x3, src/lin.rs:197-208
+void lookat(H3 dxyz, float *m)
+{
+    const H3 fwd = hnorm(dxyz);
+    const H3 right = hnorm(hcross(fwd, h3(0.0f, 0.0f, 1.0f)));
+    const H3 n_up = hcross(right, fwd);
+    const float r[9] = {right.x, -right.y, right.z, -fwd.x, fwd.y, -fwd.z, n_up.x, -n_up.y, n_up.z};
+    memcpy(m, r, sizeof r);
+}
+H3 mul3(const float *m, H3 v)
+{
+    return h3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+bool is_identity(const float *m)
+{
+    static const float id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) if (!(m[i] == id[i])) return false;
+    return true;
+}
+
+inline u32 bits(float f) { u32 u; memcpy(&u, &f, 4); return u; }
+inline float fbits(u32 u) { float f; memcpy(&f, &u, 4); return f; }
+
+struct Blob {
+    std::vector<u32> w;
+    u32 align4() { while (w.size() & 3u) w.push_back(0); return (u32)w.size(); }
+    void f(float v) { w.push_back(bits(v)); }
+    void u(u32 v) { w.push_back(v); }
+    void f3(H3 v) { f(v.x); f(v.y); f(v.z); }
+};
+
+// ---- octree, reference src/rt.rs:630-703 (BVH::gen / construct) and :227-248 (check_in_aabb) ----
+struct TNode {
+    H3 aabb, rel;
+    std::vector<u32> content;
+    std::vector<TNode> childs;
+};
+const float kSign[8][3] = {{1, 1, 1}, {-1, 1, 1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, -1}, {1, -1, -1}};
+
+bool vtx_in(H3 v, H3 hi, H3 lo)
+{
+    if (v.x > hi.x || v.y > hi.y || v.z > hi.z) return false;
+    if (v.x < lo.x || v.y < lo.y || v.z < lo.z) return false;
+    return true;
+}
+
+void construct(TNode &n, const float *tris, u32 n_tris, u32 d, u32 deep)
+{
+    if (d >= deep) {
+        const H3 hi = hadd(n.rel, hmuls(n.aabb, 0.5f));
+        const H3 lo = hsub(n.rel, hmuls(n.aabb, 0.5f));
+        for (u32 i = 0; i < n_tris; ++i) {
+            const float *t = tris + (size_t)i * 9;
+            if (vtx_in(h3(t[0], t[1], t[2]), hi, lo) || vtx_in(h3(t[3], t[4], t[5]), hi, lo) || vtx_in(h3(t[6], t[7], t[8]), hi, lo))
+                n.content.push_back(i);
+        }
+        return;
+    }
+    for (int i = 0; i < 8; ++i) {
+        TNode c;
+        c.aabb = hmuls(n.aabb, 0.5f);
+        c.rel = hadd(n.rel, hhadam(n.aabb, hmuls(h3(kSign[i][0], kSign[i][1], kSign[i][2]), 0.25f)));
+        construct(c, tris, n_tris, d + 1, deep);
+        if (!c.content.empty() || !c.childs.empty()) n.childs.push_back(std::move(c));
+    }
+}
+
+void put_node(std::vector<float> &nodes, u32 idx, const TNode &n, u32 first, u32 count_word)
+{
+    float *q = nodes.data() + (size_t)idx * NODE_WORDS;
+    const H3 half = hmuls(n.aabb, 0.5f);
+    q[NODE_HALF] = half.x; q[NODE_HALF + 1] = half.y; q[NODE_HALF + 2] = half.z;
+    q[NODE_REL] = n.rel.x; q[NODE_REL + 1] = n.rel.y; q[NODE_REL + 2] = n.rel.z;
+    q[NODE_FIRST] = fbits(first);
+    q[NODE_COUNT] = fbits(count_word);
+}
+
+// children of a node occupy consecutive slots, in the reference's child order
+void flatten(const TNode &n, u32 idx, OctreeFlat &out)
+{
+    if (!n.content.empty()) {
+        const u32 first = (u32)out.leaf_ids.size();
+        out.leaf_ids.insert(out.leaf_ids.end(), n.content.begin(), n.content.end());
+        put_node(out.nodes, idx, n, first, (u32)n.content.size() | 0x80000000u);
+        return;
+    }
+    const u32 first = (u32)(out.nodes.size() / NODE_WORDS);
+    out.nodes.resize(out.nodes.size() + n.childs.size() * NODE_WORDS);
+    put_node(out.nodes, idx, n, first, (u32)n.childs.size());
+    for (size_t i = 0; i < n.childs.size(); ++i) flatten(n.childs[i], first + (u32)i, out);
+}
+
+}  // namespace
+
+void build_octree(const float *tris, u32 n_tris, OctreeFlat &out)
+{
+    out = OctreeFlat();
+    if (n_tris == 0) return;                       // Mesh::gen_aabb -> None, src/rt.rs:261-270
+    // 2 * max |coordinate| per axis; max_by(total_cmp) over sign-cleared floats == max of the bit patterns
+    u32 mx = 0, my = 0, mz = 0;
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i) {
+        const u32 ax = bits(fabsf(tris[i * 3])), ay = bits(fabsf(tris[i * 3 + 1])), az = bits(fabsf(tris[i * 3 + 2]));
+        if (ax > mx) mx = ax;
+        if (ay > my) my = ay;
+        if (az > mz) mz = az;
+    }
+    TNode root;
+    root.aabb = h3(2.0f * fbits(mx), 2.0f * fbits(my), 2.0f * fbits(mz));
+    root.rel = h3(0.0f, 0.0f, 0.0f);
+    construct(root, tris, n_tris, 0, 3);           // BVH::gen(aabb, &mesh, 3), src/parser.rs:816
+    if (root.content.empty() && root.childs.empty()) { out.empty_root = true; return; }
+    out.nodes.resize(NODE_WORDS);
+    out.root = 0;
+    flatten(root, 0, out);
+}
+
+// image 0.24 imageops::sample: per-output-index taps of horizontal_sample / vertical_sample
+void lanczos3_taps(u32 src, u32 dst, ResampleTaps &out)
+{
+    const float ratio = (float)src / (float)dst;
+    const float sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float support = 3.0f * sratio;
+    out.cap = (u32)(2.0f * support) + 4;
+    out.left.assign(dst, 0);
+    out.count.assign(dst, 0);
+    out.weight.assign((size_t)dst * out.cap, 0.0f);
+    auto sinc = [](float t) { const float a = t * kPi; return (t == 0.0f) ? 1.0f : sinf(a) / a; };
+    auto kernel = [&](float x) { return (fabsf(x) < 3.0f) ? sinc(x) * sinc(x / 3.0f) : 0.0f; };
+    for (u32 o = 0; o < dst; ++o) {
+        float input = ((float)o + 0.5f) * ratio;
+        long long left = (long long)floorf(input - support);
+        if (left < 0) left = 0;
+        if (left > (long long)src - 1) left = (long long)src - 1;
+        long long right = (long long)ceilf(input + support);
+        if (right < left + 1) right = left + 1;
+        if (right > (long long)src) right = (long long)src;
+        input = input - 0.5f;
+        u32 n = (u32)(right - left);
+        if (n > out.cap) n = out.cap;               // cannot happen: cap >= 2*support + 2
+        float *w = out.weight.data() + (size_t)o * out.cap;
+        float sum = 0.0f;
+        for (u32 i = 0; i < n; ++i) { w[i] = kernel(((float)(left + i) - input) / sratio); sum += w[i]; }
+        for (u32 i = 0; i < n; ++i) w[i] /= sum;
+        out.left[o] = (u32)left;
+        out.count[o] = n;
+    }
+}
+
+namespace {
+
+inline float min_num(float a, float b) { if (a != a) return b; if (b != b) return a; return b < a ? b : a; }
+inline bool unit(float v) { return v >= 0.0f && v <= 1.0f; }
+
+u32 to_usize_u32(float v)   // (res as f32 * ssaa) as usize, src/sampler.rs:29-30
+{
+    if (!(v > 0.0f)) return 0;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (u32)v;
+}
+
+}  // namespace
+
+int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
+{
+    char msg[256];
+    if (!d) { err = "null render description"; return MRT_ERR_ARG; }
+    const mrt_scene &sc = d->scene;
+    if ((sc.n_renderer && !sc.renderer) || (sc.n_light && !sc.light) || (sc.n_textures && !sc.textures)) {
+        err = "null array with non-zero count"; return MRT_ERR_ARG;
+    }
+    out = Packed();
+    Params &P = out.P;
+    memset(&P, 0, sizeof P);
+
+    // ---- frame ----
+    const mrt_frame &fr = d->frame;
+    out.res_w = fr.res_w; out.res_h = fr.res_h;
+    out.gamma = fr.cam.gamma; out.exp = fr.cam.exp;
+    P.w = (float)fr.res_w * fr.ssaa;
+    P.h = (float)fr.res_h * fr.ssaa;
+    out.nw = to_usize_u32(P.w);
+    out.nh = to_usize_u32(P.h);
+    if (out.nw == 0 || out.nh == 0) { err = "empty frame (res * ssaa truncates to 0)"; return MRT_ERR_SCENE; }
+    if ((unsigned long long)out.nw * out.nh > 0xffffffffull) { err = "frame has more than 2^32 supersampled pixels"; return MRT_ERR_LIMIT; }
+    P.nw = out.nw; P.nh = out.nh;
+    P.aspect = P.w / P.h;
+    const float tan_fov = tanf((0.5f * fr.cam.fov) * (kPi / 180.0f));    // f32::to_radians().tan(), src/rt.rs:902
+    P.inv2tan = 1.0f / (2.0f * tan_fov);
+    for (int k = 0; k < 3; ++k) P.cam_pos[k] = fr.cam.pos[k];
+    P.aprt = fr.cam.aprt; P.foc = fr.cam.foc;
+    lookat(h3(fr.cam.dir[1], fr.cam.dir[2], fr.cam.dir[3]), P.cam_L);
+    rotate_y(fr.cam.dir[0], P.cam_R);
+    P.bounce = d->rt.bounce;
+    if (P.bounce > 0x0fffffffu) { err = "bounce too large"; return MRT_ERR_LIMIT; }
+    P.q = 1.0f - min_num(d->rt.loss, 1.0f);
+    for (int k = 0; k < 3; ++k) { P.sky[k] = sc.sky.color[k]; P.sky_init[k] = sc.sky.color[k] * sc.sky.pwr; }
+
+    // ---- validation: everything the reference would panic on is refused here ----
+    for (u32 t = 0; t < sc.n_textures; ++t) {
+        const mrt_texture &tx = sc.textures[t];
+        if (tx.dat && ((unsigned long long)tx.w * tx.h == 0 || (unsigned long long)tx.w * tx.h > 0x7fffffffull)) {
+            snprintf(msg, sizeof msg, "texture %u: %ux%u texels (reference would index out of bounds, src/rt.rs:624)", t, tx.w, tx.h);
+            err = msg; return MRT_ERR_SCENE;
+        }
+    }
+    for (u32 r = 0; r < sc.n_renderer; ++r) {
+        const mrt_renderer &o = sc.renderer[r];
+        if (o.kind > MRT_KIND_MESH) { snprintf(msg, sizeof msg, "renderer %u: unknown kind %u", r, o.kind); err = msg; return MRT_ERR_SCENE; }
+        if (o.n_inst && !o.inst) { err = "null instance array"; return MRT_ERR_ARG; }
+        if (o.kind == MRT_KIND_MESH && o.n_tris && !o.tris) { err = "null triangle array"; return MRT_ERR_ARG; }
+        const int32_t maps[6] = {o.mat.tex, o.mat.rmap, o.mat.mmap, o.mat.gmap, o.mat.omap, o.mat.emap};
+        for (int k = 0; k < 6; ++k) {
+            if (maps[k] >= (int32_t)sc.n_textures) { snprintf(msg, sizeof msg, "renderer %u: map %d index out of range", r, k); err = msg; return MRT_ERR_SCENE; }
+            if (maps[k] >= 0 && (o.kind == MRT_KIND_TRIANGLE || o.kind == MRT_KIND_MESH)) {
+                snprintf(msg, sizeof msg, "renderer %u: texture maps on a triangle/mesh hit todo!() in the reference (src/rt.rs:546,806)", r);
+                err = msg; return MRT_ERR_SCENE;
+            }
+        }
+        if (o.mat.emap < 0 && !unit(o.mat.emit)) {
+            snprintf(msg, sizeof msg, "renderer %u: emit %g outside [0,1] (gen_bool panics, src/rt.rs:968)", r, (double)o.mat.emit); err = msg; return MRT_ERR_SCENE;
+        }
+        if (o.mat.omap < 0 && min_num(1.0f - o.mat.opacity, 0.85f) < 0.0f) {
+            snprintf(msg, sizeof msg, "renderer %u: opacity %g > 1 (gen_bool panics, src/rt.rs:1054)", r, (double)o.mat.opacity); err = msg; return MRT_ERR_SCENE;
+        }
+        if (o.mat.emap >= 0 && sc.textures[o.mat.emap].dat) {
+            const mrt_texture &tx = sc.textures[o.mat.emap];
+            for (size_t i = 0; i < (size_t)tx.w * tx.h; ++i) if (!unit(tx.dat[i * 3])) { err = "emap texel outside [0,1] (gen_bool panics, src/rt.rs:968)"; return MRT_ERR_SCENE; }
+        }
+        if (o.mat.omap >= 0 && sc.textures[o.mat.omap].dat) {
+            const mrt_texture &tx = sc.textures[o.mat.omap];
+            for (size_t i = 0; i < (size_t)tx.w * tx.h; ++i) if (min_num(1.0f - tx.dat[i * 3], 0.85f) < 0.0f) { err = "omap texel > 1 (gen_bool panics, src/rt.rs:1054)"; return MRT_ERR_SCENE; }
+        }
+    }
+
+    // ---- tables ----
+    Blob B;
+    std::map<std::array<u32, 4>, u32> xf_index;
+    std::vector<float> xf_tab;
+    auto xf_of = [&](const float *dir) -> u32 {
+        std::array<u32, 4> key = {bits(dir[0]), bits(dir[1]), bits(dir[2]), bits(dir[3])};
+        auto it = xf_index.find(key);
+        if (it != xf_index.end()) return it->second;
+        float rec[XF_WORDS] = {0};
+        // objects use -inst.dir, src/rt.rs:726-727
+        lookat(h3(-dir[1], -dir[2], -dir[3]), rec + XF_L);
+        rotate_y(-dir[0], rec + XF_R);
+        rec[XF_IDENT] = fbits((is_identity(rec + XF_L) && is_identity(rec + XF_R)) ? 1u : 0u);
+        const u32 id = (u32)(xf_tab.size() / XF_WORDS);
+        xf_tab.insert(xf_tab.end(), rec, rec + XF_WORDS);
+        xf_index[key] = id;
+        return id;
+    };
+
+    std::vector<u32> rend_tab, inst_tab, mat_tab, mesh_tab, leaf_tab;
+    std::vector<float> tri_tab, node_tab;
+    u32 n_inst_total = 0;
+    for (u32 r = 0; r < sc.n_renderer; ++r) {
+        const mrt_renderer &o = sc.renderer[r];
+        u32 rec[REND_WORDS] = {0};
+        rec[REND_KIND] = o.kind;
+        rec[REND_INST_OFF] = n_inst_total;
+        rec[REND_INST_CNT] = o.n_inst;
+        const int32_t maps[6] = {o.mat.tex, o.mat.rmap, o.mat.mmap, o.mat.gmap, o.mat.omap, o.mat.emap};
+        bool any_map = false;
+        for (int k = 0; k < 6; ++k) any_map |= maps[k] >= 0;
+        rec[REND_FLAGS] = any_map ? RF_HAS_MAPS : 0u;
+        H3 nn = h3(0, 0, 0), nraw = h3(0, 0, 0);
+        if (o.kind == MRT_KIND_SPHERE) {
+            rec[REND_GEO] = bits(o.param[0] * o.param[0]);
+        } else if (o.kind == MRT_KIND_PLANE) {
+            nraw = h3(o.param[0], o.param[1], o.param[2]);
+            nn = hnorm(nraw);
+            rec[REND_GEO] = bits(nn.x); rec[REND_GEO + 1] = bits(nn.y); rec[REND_GEO + 2] = bits(nn.z);
+            rec[REND_GEO + 3] = bits(nraw.x); rec[REND_GEO + 4] = bits(nraw.y); rec[REND_GEO + 5] = bits(nraw.z);
+        } else if (o.kind == MRT_KIND_BOX) {
+            const H3 sz = h3(o.param[0], o.param[1], o.param[2]);
+            const H3 half = hmuls(sz, 0.5f);
+            const H3 inv2 = hmuls(h3(1.0f / sz.x, 1.0f / sz.y, 1.0f / sz.z), 2.0f);
+            rec[REND_GEO] = bits(half.x); rec[REND_GEO + 1] = bits(half.y); rec[REND_GEO + 2] = bits(half.z);
+            rec[REND_GEO + 3] = bits(inv2.x); rec[REND_GEO + 4] = bits(inv2.y); rec[REND_GEO + 5] = bits(inv2.z);
+        } else if (o.kind == MRT_KIND_TRIANGLE) {
+            const H3 a = h3(o.param[0], o.param[1], o.param[2]), b = h3(o.param[3], o.param[4], o.param[5]), c = h3(o.param[6], o.param[7], o.param[8]);
+            const H3 e0 = hsub(b, a), e1 = hsub(c, a);
+            const float g[9] = {a.x, a.y, a.z, e0.x, e0.y, e0.z, e1.x, e1.y, e1.z};
+            for (int k = 0; k < 9; ++k) rec[REND_GEO + k] = bits(g[k]);
+        } else {
+            const u32 mesh_id = (u32)(mesh_tab.size() / MESH_WORDS);
+            rec[REND_GEO] = mesh_id;
+            OctreeFlat oc;
+            build_octree(o.tris, o.n_tris, oc);
+            if (oc.empty_root) {
+                snprintf(msg, sizeof msg, "renderer %u: mesh octree is empty (reference unwrap() panics, src/rt.rs:717)", r);
+                err = msg; return MRT_ERR_SCENE;
+            }
+            const u32 node0 = (u32)(node_tab.size() / NODE_WORDS);
+            const u32 leaf0 = (u32)leaf_tab.size();
+            // node-relative child indices -> absolute node indices
+            for (size_t n = 0; n < oc.nodes.size() / NODE_WORDS; ++n) {
+                float *q = oc.nodes.data() + n * NODE_WORDS;
+                if (!(bits(q[NODE_COUNT]) & 0x80000000u)) q[NODE_FIRST] = fbits(bits(q[NODE_FIRST]) + node0);
+            }
+            mesh_tab.push_back((u32)(tri_tab.size() / TRI_WORDS));
+            mesh_tab.push_back(o.n_tris);
+            mesh_tab.push_back(oc.root == NO_NODE ? NO_NODE : node0 + oc.root);
+            mesh_tab.push_back(leaf0);
+            node_tab.insert(node_tab.end(), oc.nodes.begin(), oc.nodes.end());
+            leaf_tab.insert(leaf_tab.end(), oc.leaf_ids.begin(), oc.leaf_ids.end());
+            for (u32 t = 0; t < o.n_tris; ++t) {
+                const float *p = o.tris + (size_t)t * 9;
+                const H3 a = h3(p[0], p[1], p[2]), b = h3(p[3], p[4], p[5]), c = h3(p[6], p[7], p[8]);
+                const H3 e0 = hsub(b, a), e1 = hsub(c, a);
+                const float g[9] = {a.x, a.y, a.z, e0.x, e0.y, e0.z, e1.x, e1.y, e1.z};
+                tri_tab.insert(tri_tab.end(), g, g + 9);
+            }
+        }
+        rend_tab.insert(rend_tab.end(), rec, rec + REND_WORDS);
+
+        for (u32 i = 0; i < o.n_inst; ++i) {
+            const mrt_instance &in = o.inst[i];
+            u32 ir[INST_WORDS] = {0};
+            const H3 pos = h3(in.pos[0], in.pos[1], in.pos[2]);
+            ir[INST_POS] = bits(pos.x); ir[INST_POS + 1] = bits(pos.y); ir[INST_POS + 2] = bits(pos.z);
+            const u32 xf = xf_of(in.dir);
+            ir[INST_XF] = xf;
+            if (o.kind == MRT_KIND_PLANE) {
+                ir[INST_PLANE_D] = bits(hdot(hneg(nn), pos));                                   // src/rt.rs:404
+                const float *X = xf_tab.data() + (size_t)xf * XF_WORDS;
+                const H3 nw = hnorm(mul3(X + XF_R, mul3(X + XF_L, nraw)));                      // src/rt.rs:786,792
+                ir[INST_PLANE_NW] = bits(nw.x); ir[INST_PLANE_NW + 1] = bits(nw.y); ir[INST_PLANE_NW + 2] = bits(nw.z);
+            }
+            inst_tab.insert(inst_tab.end(), ir, ir + INST_WORDS);
+        }
+        n_inst_total += o.n_inst;
+
+        u32 mr[MAT_WORDS] = {0};
+        mr[MAT_ALBEDO] = bits(o.mat.albedo[0]); mr[MAT_ALBEDO + 1] = bits(o.mat.albedo[1]); mr[MAT_ALBEDO + 2] = bits(o.mat.albedo[2]);
+        mr[MAT_ROUGH] = bits(o.mat.rough); mr[MAT_METAL] = bits(o.mat.metal); mr[MAT_GLASS] = bits(o.mat.glass);
+        mr[MAT_OPACITY] = bits(o.mat.opacity); mr[MAT_EMIT] = bits(o.mat.emit);
+        for (int k = 0; k < 6; ++k) mr[MAT_MAP + k] = (u32)maps[k];
+        mat_tab.insert(mat_tab.end(), mr, mr + MAT_WORDS);
+    }
+    if (xf_tab.empty()) { const float dflt[4] = {-0.0f, -0.0f, -1.0f, -0.0f}; xf_of(dflt); }
+
+    P.n_rend = sc.n_renderer; P.n_inst = n_inst_total; P.n_light = sc.n_light;
+    P.off_rend = B.align4(); B.w.insert(B.w.end(), rend_tab.begin(), rend_tab.end());
+    P.off_inst = B.align4(); B.w.insert(B.w.end(), inst_tab.begin(), inst_tab.end());
+    P.off_xf = B.align4(); for (float v : xf_tab) B.f(v);
+    P.off_mat = B.align4(); B.w.insert(B.w.end(), mat_tab.begin(), mat_tab.end());
+    P.off_light = B.align4();
+    for (u32 l = 0; l < sc.n_light; ++l) {
+        const mrt_light &li = sc.light[l];
+        if (li.kind > MRT_LIGHT_DIR) { err = "unknown light kind"; return MRT_ERR_SCENE; }
+        B.u(li.kind);
+        if (li.kind == MRT_LIGHT_POINT) B.f3(h3(li.v[0], li.v[1], li.v[2]));
+        else B.f3(hnorm(hneg(hnorm(h3(li.v[0], li.v[1], li.v[2])))));      // (-dir.norm()).norm(), src/rt.rs:1031-1034
+        B.f(li.pwr);
+        B.f3(h3(li.color[0], li.color[1], li.color[2]));
+    }
+    // textures: RGB8 + LUT when every texel is exactly k/255 (what a decoded image file is, src/parser.rs:665)
+    P.off_tex = B.align4();
+    const u32 tex_desc0 = (u32)B.w.size();
+    B.w.resize(B.w.size() + (size_t)sc.n_textures * TEX_WORDS, 0);
+    P.off_lut = B.align4();
+    for (int k = 0; k < 256; ++k) B.f((float)k / 255.0f);
+    for (u32 t = 0; t < sc.n_textures; ++t) {
+        const mrt_texture &tx = sc.textures[t];
+        u32 *desc = B.w.data() + tex_desc0 + (size_t)t * TEX_WORDS;
+        desc[TEX_W] = tx.w; desc[TEX_H] = tx.h;
+        if (!tx.dat) { desc[TEX_FMT] = TEXFMT_NONE; continue; }
+        const size_t n = (size_t)tx.w * tx.h * 3;
+        bool exact = true;
+        for (size_t i = 0; i < n && exact; ++i) {
+            const float v = tx.dat[i];
+            const float kf = rintf(v * 255.0f);
+            exact = kf >= 0.0f && kf <= 255.0f && bits(kf / 255.0f) == bits(v);
+        }
+        const u32 off = B.align4();
+        desc = B.w.data() + tex_desc0 + (size_t)t * TEX_WORDS;   // align4 may have reallocated
+        if (exact) {
+            desc[TEX_FMT] = TEXFMT_U8; desc[TEX_OFF] = off * 4u;
+            std::vector<unsigned char> bytes(n);
+            for (size_t i = 0; i < n; ++i) bytes[i] = (unsigned char)rintf(tx.dat[i] * 255.0f);
+            const size_t words = (n + 3) / 4;
+            const size_t at = B.w.size();
+            B.w.resize(at + words, 0);
+            memcpy(B.w.data() + at, bytes.data(), n);
+            out.n_tex_u8++;
+        } else {
+            desc[TEX_FMT] = TEXFMT_F32; desc[TEX_OFF] = off;
+            for (size_t i = 0; i < n; ++i) B.f(tx.dat[i]);
+            out.n_tex_f32++;
+        }
+    }
+    P.off_mesh = B.align4(); B.w.insert(B.w.end(), mesh_tab.begin(), mesh_tab.end());
+    P.off_tri = B.align4(); for (float v : tri_tab) B.f(v);
+    P.off_node = B.align4(); for (float v : node_tab) B.f(v);
+    P.off_leaf = B.align4(); B.w.insert(B.w.end(), leaf_tab.begin(), leaf_tab.end());
+    B.align4();
+    P.blob_words = (u32)B.w.size();
+    out.blob.swap(B.w);
+    out.n_nodes = (u32)(node_tab.size() / NODE_WORDS);
+    out.n_leaf_ids = (u32)leaf_tab.size();
+    out.n_tris = (u32)(tri_tab.size() / TRI_WORDS);
+    out.n_xf = (u32)(xf_tab.size() / XF_WORDS);
+    return MRT_OK;
+}
+
+}  // namespace mrt

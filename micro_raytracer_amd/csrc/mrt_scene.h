@@ -1,0 +1,91 @@
+// mrt_scene.h — packed device layout of a flattened rt::Scene (reference src/rt.rs:82-190) and
+// the kernel parameter block.  The host packer (mrt_pack.cpp) writes this layout once per
+// mrt_create; every workgroup of the path-tracing kernel stages the whole blob into LDS.
+//
+// All tables are arrays of 32-bit words (f32 or u32); offsets are in words from the blob
+// start, 16-byte aligned.  Everything that depends only on the scene (not on the ray) is
+// hoisted here with the reference's own operation order, so the kernel reproduces the
+// reference's per-call recomputation bit for bit:
+//   plane      n^ = norm(n), d = (-n^).pos              src/rt.rs:404-405
+//   sphere     r*r                                       src/rt.rs:342
+//   box        0.5*size, (1/size)*2                      src/rt.rs:319, 416
+//   triangle   e0 = v1-v0, e1 = v2-v0                    src/rt.rs:365-366
+//   instance   R = rotate_y(-dir), L = lookat(-dir, up)  src/rt.rs:726-727
+//   light      norm(-(norm(dir))) for directional lights src/rt.rs:1031-1034
+#pragma once
+#include "mrt_math.h"
+
+namespace mrt {
+
+// ---- record sizes (words) ----
+constexpr u32 REND_WORDS = 16;
+constexpr u32 INST_WORDS = 8;
+constexpr u32 XF_WORDS = 20;
+constexpr u32 MAT_WORDS = 16;
+constexpr u32 LIGHT_WORDS = 8;
+constexpr u32 TEX_WORDS = 4;
+constexpr u32 MESH_WORDS = 4;
+constexpr u32 TRI_WORDS = 9;
+constexpr u32 NODE_WORDS = 8;
+
+// REND: [0] kind  [1] inst_off  [2] inst_cnt  [3] flags  [4..15] geometry
+enum : u32 { REND_KIND = 0, REND_INST_OFF = 1, REND_INST_CNT = 2, REND_FLAGS = 3, REND_GEO = 4 };
+enum : u32 { RF_HAS_MAPS = 1u };
+// geometry words: sphere [4] r*r | plane [4..6] n^, [7..9] n | box [4..6] half, [7..9] (1/size)*2 |
+// triangle [4..6] v0, [7..9] e0, [10..12] e1 | mesh [4] mesh index
+
+// INST: [0..2] pos  [3] plane d  [4] xf index  [5..7] plane world normal norm(R*(L*n))
+enum : u32 { INST_POS = 0, INST_PLANE_D = 3, INST_XF = 4, INST_PLANE_NW = 5 };
+
+// XF: [0..8] L (lookat)  [9..17] R (rotate_y)  [18] 1 if both equal the identity as values
+enum : u32 { XF_L = 0, XF_R = 9, XF_IDENT = 18 };
+
+// MAT: [0..2] albedo [3] rough [4] metal [5] glass [6] opacity [7] emit [8..13] map ids (tex rmap mmap gmap omap emap, -1 none)
+enum : u32 { MAT_ALBEDO = 0, MAT_ROUGH = 3, MAT_METAL = 4, MAT_GLASS = 5, MAT_OPACITY = 6, MAT_EMIT = 7, MAT_MAP = 8 };
+enum : u32 { MAP_TEX = 0, MAP_ROUGH = 1, MAP_METAL = 2, MAP_GLASS = 3, MAP_OPACITY = 4, MAP_EMIT = 5 };
+
+// LIGHT: [0] kind [1..3] point: pos / dir: norm(-(norm(dir)))  [4] pwr  [5..7] color
+enum : u32 { LIGHT_KIND = 0, LIGHT_V = 1, LIGHT_PWR = 4, LIGHT_COLOR = 5 };
+
+// TEX: [0] w [1] h [2] offset (words for f32 texels, bytes for u8 texels, from blob start) [3] format
+enum : u32 { TEX_W = 0, TEX_H = 1, TEX_OFF = 2, TEX_FMT = 3 };
+enum : u32 { TEXFMT_NONE = 0, TEXFMT_F32 = 1, TEXFMT_U8 = 2 };
+
+// MESH: [0] first triangle [1] triangle count [2] root node (0xffffffff: no octree) [3] leaf-id base
+enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3 };
+constexpr u32 NO_NODE = 0xffffffffu;
+
+// NODE: [0..2] 0.5*aabb  [3..5] rel_pos  [6] first child node | first leaf id  [7] count | leaf<<31
+enum : u32 { NODE_HALF = 0, NODE_REL = 3, NODE_FIRST = 6, NODE_COUNT = 7 };
+
+enum : u32 { KIND_SPHERE = 0, KIND_PLANE = 1, KIND_BOX = 2, KIND_TRIANGLE = 3, KIND_MESH = 4 };
+enum : u32 { LK_POINT = 0, LK_DIR = 1 };
+
+struct Params {
+    // frame / sampling
+    u32 nw, nh;
+    u32 local_rows, shard_index, shard_count, shard_rows;
+    u32 n_samples, sample_base;
+    u32 seed_lo, seed_hi;
+    u32 bounce;
+    float q;                 // 1 - min(loss, 1), src/rt.rs:571
+    float w, h, aspect;      // src/rt.rs:938-940
+    float inv2tan;           // 1 / (2 tan(rad(fov/2))), src/rt.rs:902-906
+    float cam_pos[3];
+    float aprt, foc;
+    float cam_L[9], cam_R[9];   // lookat(cam.dir, up), rotate_y(cam.dir), src/rt.rs:925-927
+    float sky[3];
+    float sky_init[3];       // sky.color * sky.pwr, src/rt.rs:964
+    // scene tables
+    u32 n_rend, n_light, n_inst;
+    u32 off_rend, off_inst, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
+    u32 blob_words;
+    u32 tiles_x, tiles_y;    // 8x8-pixel wave tiles per workgroup in x and y
+    u32 count_segments;
+    // device pointers
+    const u32 *blob;
+    float *accum;            // [local_rows][nw][3]
+    unsigned long long *segments;
+};
+
+}  // namespace mrt

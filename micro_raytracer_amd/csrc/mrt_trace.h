@@ -1,0 +1,600 @@
+// mrt_trace.h — the per-lane path tracer of the gfx950 megakernel.
+//
+// One lane owns one supersampled pixel and walks all samples of a launch with path
+// regeneration: as soon as a path ends the lane starts its next sample, so a wavefront only
+// idles at the very end of the launch.  The scene is read from the LDS-staged blob
+// (mrt_scene.h); the traversal loop over renderers x instances is wave-uniform, so those
+// reads are LDS broadcasts and all divergence is in per-lane predicates.
+//
+// Behaviour follows the reference function by function (file:line in each comment, paths
+// relative to the reference checkout).  Geometry (everything that feeds a hit / miss or a
+// coin flip) keeps the reference's f32 operation order exactly; radiance is accumulated
+// front-to-back instead of the reference's back-to-front fold (src/rt.rs:964-993), which is
+// the same affine recurrence evaluated in the other direction.
+#pragma once
+#include "mrt_scene.h"
+
+namespace mrt {
+
+constexpr float kE = 0.0001f;                 // src/rt.rs:7
+constexpr float kBig = 1.0f / 0.0001f;        // E.recip(), src/rt.rs:307
+
+struct V3 { float x, y, z; };
+MRT_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+MRT_HD V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }                 // lin.rs:211-221
+MRT_HD V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }                 // lin.rs:247-257
+MRT_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                // lin.rs:259-264
+MRT_HD V3 muls(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }                   // lin.rs:266-275
+MRT_HD V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }                                      // lin.rs:304-314
+MRT_HD V3 hadam(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }               // lin.rs:107-113
+MRT_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); } // lin.rs:52-58
+MRT_HD float mag(V3 a) { return sqrt_(a.x * a.x + a.y * a.y + a.z * a.z); }               // lin.rs:60-62
+MRT_HD V3 norm(V3 a) { return muls(a, recip_(mag(a))); }                                  // lin.rs:64-66
+MRT_HD V3 reflect(V3 d, V3 n) { return sub(d, muls(n, 2.0f * dot(d, n))); }               // lin.rs:68-70
+MRT_HD V3 m3mul(const float *m, V3 v)                                                     // lin.rs:344-365
+{
+    return v3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+MRT_HD V3 ld3(const float *F, u32 i) { return v3(F[i], F[i + 1], F[i + 2]); }
+MRT_HD u32 ldu(const float *F, u32 i) { return f2u(F[i]); }
+
+// true when x is neither zero, infinite nor NaN
+MRT_HD bool nzfin(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_classf(x, 0x198);   // -normal | -denormal | +denormal | +normal
+#else
+    const float a = fabs_(x);
+    return a > 0.0f && a < kInf;
+#endif
+}
+MRT_HD bool nzfin3(V3 v) { return nzfin(v.x) && nzfin(v.y) && nzfin(v.z); }
+
+// rot_y * (look * v), src/rt.rs:730-731, 782, 792, 798.  When both matrices equal the identity as
+// values (default instance direction) and no component of v is zero / non-finite the two products
+// return v bit for bit, so they are skipped; signed zeros and NaNs take the full route.
+MRT_HD V3 xf_full(const float *X, V3 v) { return m3mul(X + XF_R, m3mul(X + XF_L, v)); }
+MRT_HD V3 xf_vec(const float *X, bool ident, V3 v)
+{
+    if (ident && nzfin3(v)) return v;
+    return xf_full(X, v);
+}
+
+MRT_HD V3 recip_patched(V3 d)   // Box::intersect's 1/dir with inf -> 1/E, src/rt.rs:303-316
+{
+    V3 m = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (fabs_(m.x) == kInf) m.x = kBig;
+    if (fabs_(m.y) == kInf) m.y = kBig;
+    if (fabs_(m.z) == kInf) m.z = kBig;
+    return m;
+}
+
+// Box::intersect, src/rt.rs:299-333, with m = recip_patched(dir) and half = 0.5 * sizes
+MRT_HD bool box_isect(V3 half, V3 ro, V3 m, V3 pos, float &t0, float &t1)
+{
+    const V3 n = hadam(sub(ro, pos), m);
+    const V3 k = hadam(half, v3(fabs_(m.x), fabs_(m.y), fabs_(m.z)));
+    const V3 a = sub(neg(n), k);
+    const V3 b = add(neg(n), k);
+    t0 = fmax_(fmax_(a.x, a.y), a.z);
+    t1 = fmin_(fmin_(b.x, b.y), b.z);
+    return !(t0 > t1 || t1 < 0.0f);
+}
+
+// Sphere::intersect, src/rt.rs:335-359; oo = ray.orig - pos, a = dir.dir
+MRT_HD bool sphere_isect(float r2, V3 oo, V3 rd, float a, float &t0, float &t1)
+{
+    const float b = 2.0f * dot(oo, rd);
+    const float c = dot(oo, oo) - r2;
+    const float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f) return false;
+    const float sq = sqrt_(disc);
+    const float q0 = (-b - sq) / (2.0f * a);
+    if (q0 < 0.0f) return false;
+    t0 = q0;
+    t1 = (-b + sq) / (2.0f * a);
+    return true;
+}
+
+// Triangle::intersect, src/rt.rs:361-398; vp = v0 + pos
+MRT_HD bool tri_isect(V3 vp, V3 e0, V3 e1, V3 ro, V3 rd, float &t)
+{
+    const V3 p = cross(rd, e1);
+    const float d = dot(e0, p);
+    if (d < kE && d > -kE) return false;
+    const float inv_d = recip_(d);
+    const V3 tv = sub(ro, vp);
+    const float u = dot(tv, p) * inv_d;
+    if (u < 0.0f || u > 1.0f) return false;
+    const V3 q = cross(tv, e0);
+    const float v = dot(rd, q) * inv_d;
+    if (v < 0.0f || (u + v) > 1.0f) return false;
+    const float tt = dot(e1, q) * inv_d;
+    if (tt < 0.0f) return false;
+    t = tt;
+    return true;
+}
+
+// Plane::intersect, src/rt.rs:400-412; nn = norm(n), d = (-nn).pos
+MRT_HD bool plane_isect(V3 nn, float d, V3 ro, V3 rd, float &t)
+{
+    const float tt = -(dot(ro, nn) + d) / dot(rd, nn);
+    if (tt <= 0.0f) return false;
+    t = tt;
+    return true;
+}
+
+MRT_HD bool in_range(float lo, float hi, float x) { return lo <= x && x < hi; }
+
+// Normal for Box, src/rt.rs:414-445 (x / y else-if chain, then an independent z chain that overrides)
+MRT_HD V3 box_normal(V3 inv2, V3 hit, V3 pos)
+{
+    const V3 p = hadam(sub(hit, pos), inv2);
+    const float plo = 1.0f - kE, phi = 1.0f + kE, nlo = -1.0f - kE, nhi = -1.0f + kE;
+    V3 n = v3(0.0f, 0.0f, 0.0f);
+    if (in_range(plo, phi, p.x)) n = v3(1.0f, 0.0f, 0.0f);
+    else if (in_range(nlo, nhi, p.x)) n = v3(-1.0f, -0.0f, -0.0f);
+    else if (in_range(plo, phi, p.y)) n = v3(0.0f, 1.0f, 0.0f);
+    else if (in_range(nlo, nhi, p.y)) n = v3(-0.0f, -1.0f, -0.0f);
+    if (in_range(plo, phi, p.z)) n = v3(0.0f, 0.0f, 1.0f);
+    else if (in_range(nlo, nhi, p.z)) n = v3(-0.0f, -0.0f, -1.0f);
+    return n;
+}
+
+struct UV { float x, y; };
+
+// UV for Box (4x3 cross atlas), src/rt.rs:468-516
+MRT_HD UV box_uv(V3 inv2, V3 hit, V3 pos)
+{
+    const V3 p = hadam(sub(hit, pos), inv2);
+    const float plo = 1.0f - kE, phi = 1.0f + kE, nlo = -1.0f - kE, nhi = -1.0f + kE;
+    UV r;
+    if (in_range(plo, phi, p.x)) { r.x = (0.5f + 0.5f * p.y) / 4.0f + 2.0f / 4.0f; r.y = (0.5f - 0.5f * p.z) / 3.0f + 1.0f / 3.0f; }
+    else if (in_range(nlo, nhi, p.x)) { r.x = (0.5f - 0.5f * p.y) / 4.0f; r.y = (0.5f - 0.5f * p.z) / 3.0f + 1.0f / 3.0f; }
+    else if (in_range(plo, phi, p.y)) { r.x = (0.5f - 0.5f * p.x) / 4.0f + 3.0f / 4.0f; r.y = (0.5f - 0.5f * p.z) / 3.0f + 1.0f / 3.0f; }
+    else if (in_range(nlo, nhi, p.y)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = (0.5f - 0.5f * p.z) / 3.0f + 1.0f / 3.0f; }
+    else if (in_range(plo, phi, p.z)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = (0.5f - 0.5f * p.y) / 3.0f; }
+    else if (in_range(nlo, nhi, p.z)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = (0.5f + 0.5f * p.y) / 3.0f + 2.0f / 3.0f; }
+    else { r.x = 0.0f; r.y = 0.0f; }
+    return r;
+}
+
+MRT_HD float fract_(float x) { return x - trunc_(x); }
+
+// `f32 as usize`, saturating, NaN -> 0, capped at 2^31 (so that x + y*w fits 64 bits)
+MRT_HD uint64_t to_index(float v)
+{
+    if (!(v > 0.0f)) return 0;
+    if (v >= 2147483648.0f) return 2147483648ull;
+    return (uint64_t)(u32)v;
+}
+
+struct Scn {
+    const float *F;      // the packed scene (LDS)
+    const Params *P;
+};
+
+// Texture::get_color, src/rt.rs:618-628; the flat index is clamped to the last texel where the
+// reference would panic (documented divergence).  Returns all three channels.
+MRT_HD V3 tex_fetch(const Scn &S, i32 id, UV uv)
+{
+    const float *T = S.F + S.P->off_tex + (u32)id * TEX_WORDS;
+    const u32 w = ldu(T, TEX_W), h = ldu(T, TEX_H), fmt = ldu(T, TEX_FMT), off = ldu(T, TEX_OFF);
+    if (fmt == TEXFMT_NONE) return v3(0.0f, 0.0f, 0.0f);
+    const uint64_t x = to_index(uv.x * (float)w);
+    const uint64_t y = to_index(uv.y * (float)h);
+    uint64_t idx = x + y * (uint64_t)w;
+    const uint64_t last = (uint64_t)w * h - 1;
+    if (idx > last) idx = last;
+    const u32 i = (u32)idx;
+    if (fmt == TEXFMT_U8) {
+        const unsigned char *B = reinterpret_cast<const unsigned char *>(S.F) + off + i * 3u;
+        const float *L = S.F + S.P->off_lut;
+        return v3(L[B[0]], L[B[1]], L[B[2]]);
+    }
+    return ld3(S.F, off + i * 3u);
+}
+
+// ---- one closest-hit candidate ----
+struct Hit {
+    i32 rend;      // renderer index, -1 = none
+    u32 inst;      // flattened instance index
+    float t0, t1;
+    i32 i0, i1;    // mesh triangle ids of the entry / exit hit
+};
+
+struct RayPre {
+    V3 o, d;
+    V3 m;          // recip_patched(d) (valid when the scene has boxes or meshes)
+    float dd;      // d.d
+    bool d_ok;     // nzfin3(d)
+};
+
+MRT_HD RayPre ray_pre(V3 o, V3 d)
+{
+    RayPre r;
+    r.o = o; r.d = d;
+    r.m = recip_patched(d);
+    r.dd = dot(d, d);
+    r.d_ok = nzfin3(d);
+    return r;
+}
+
+// Mesh arm of Renderer::intersect with the octree walk of intersect_bvh, src/rt.rs:707-723, 740-772.
+// The candidate list is consumed in the reference's order (leaf lists of hit leaves, concatenated,
+// consecutive duplicates dropped) without being materialised.
+template <bool ANY>
+MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
+{
+    const float *F = S.F;
+    const float *M = F + S.P->off_mesh + mesh * MESH_WORDS;
+    const u32 tri0 = ldu(M, MESH_TRI0), ntri = ldu(M, MESH_NTRI), root = ldu(M, MESH_ROOT), leaf0 = ldu(M, MESH_LEAF0);
+    bool any = false;
+    i32 k0 = 0, k1 = 0;
+    u32 last_id = 0xffffffffu;
+
+    auto test = [&](u32 id) {
+        if (id == last_id) return;          // Vec::dedup (src/rt.rs:756)
+        last_id = id;
+        const float *T = F + S.P->off_tri + (tri0 + id) * TRI_WORDS;
+        float t;
+        if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t)) return;
+        const i32 k = total_key(t);
+        if (!any) { any = true; t0 = t1 = t; i0 = i1 = (i32)id; k0 = k1 = k; return; }
+        if (k < k0) { k0 = k; t0 = t; i0 = (i32)id; }      // min_by: first minimum, src/rt.rs:764
+        if (k >= k1) { k1 = k; t1 = t; i1 = (i32)id; }     // max_by: last maximum, src/rt.rs:765
+    };
+
+    if (root == NO_NODE) {
+        for (u32 i = 0; i < ntri; ++i) { test(i); if (ANY && any) return true; }
+        return any;
+    }
+    // depth <= 3 (BVH::gen(.., 3), src/parser.rs:816): explicit stack of child ranges
+    u32 cur[4], end[4];
+    int sp = 0;
+    cur[0] = root; end[0] = root + 1;
+    bool root_hit = false;
+    while (sp >= 0) {
+        if (cur[sp] == end[sp]) { --sp; continue; }
+        const u32 node = cur[sp]++;
+        const float *N = F + S.P->off_node + node * NODE_WORDS;
+        float a0, a1;
+        if (!box_isect(ld3(N, NODE_HALF), ro, m, add(pos, ld3(N, NODE_REL)), a0, a1)) continue;
+        if (node == root) root_hit = true;
+        const u32 first = ldu(N, NODE_FIRST), cnt = ldu(N, NODE_COUNT);
+        if (cnt & 0x80000000u) {
+            const u32 n = cnt & 0x7fffffffu;
+            for (u32 i = 0; i < n; ++i) { test(ldu(F, S.P->off_leaf + leaf0 + first + i)); if (ANY && any) return true; }
+        } else if (sp < 3) {
+            ++sp;
+            cur[sp] = first; end[sp] = first + cnt;
+        }
+    }
+    (void)root_hit;
+    return any;
+}
+
+// RayTracer::closest_hit, src/rt.rs:867-898: every renderer x instance in order, first minimum of
+// the entry distance under f32::total_cmp.  ANY = true answers only Some / None (the shadow query
+// of src/rt.rs:1036).
+template <bool ANY>
+MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
+{
+    const float *F = S.F;
+    const Params &P = *S.P;
+    i32 best_key = 0x7fffffff;
+    best.rend = -1;
+    for (u32 r = 0; r < P.n_rend; ++r) {
+        const float *R = F + P.off_rend + r * REND_WORDS;
+        const u32 kind = ldu(R, REND_KIND), ioff = ldu(R, REND_INST_OFF), icnt = ldu(R, REND_INST_CNT);
+        for (u32 i = ioff; i < ioff + icnt; ++i) {
+            const float *I = F + P.off_inst + i * INST_WORDS;
+            const V3 pos = ld3(I, INST_POS);
+            const float *X = F + P.off_xf + ldu(I, INST_XF) * XF_WORDS;
+            const bool ident = ldu(X, XF_IDENT) != 0;
+            // Renderer::intersect, src/rt.rs:725-733: n_ray.orig = pos + R*(L*(orig - pos)), n_ray.dir = R*(L*dir)
+            const V3 ro = add(pos, xf_vec(X, ident, sub(ray.o, pos)));
+            const bool fast_d = ident && ray.d_ok;
+            V3 rd = ray.d, m = ray.m;
+            float dd = ray.dd;
+            if (!fast_d) {
+                rd = xf_full(X, ray.d);
+                m = recip_patched(rd);
+                dd = dot(rd, rd);
+            }
+            float t0 = 0.0f, t1 = 0.0f;
+            i32 i0 = -1, i1 = -1;
+            bool hit;
+            if (kind == KIND_SPHERE) {
+                hit = sphere_isect(R[REND_GEO], sub(ro, pos), rd, dd, t0, t1);
+            } else if (kind == KIND_PLANE) {
+                hit = plane_isect(ld3(R, REND_GEO), I[INST_PLANE_D], ro, rd, t0);
+                t1 = t0;
+            } else if (kind == KIND_BOX) {
+                hit = box_isect(ld3(R, REND_GEO), ro, m, pos, t0, t1);
+            } else if (kind == KIND_TRIANGLE) {
+                hit = tri_isect(add(ld3(R, REND_GEO), pos), ld3(R, REND_GEO + 3), ld3(R, REND_GEO + 6), ro, rd, t0);
+                t1 = t0;
+            } else {
+                hit = mesh_isect<ANY>(S, ldu(R, REND_GEO), ro, rd, m, pos, t0, i0, t1, i1);
+            }
+            if (hit) {
+                if (ANY) return true;
+                const i32 key = total_key(t0);
+                if (best.rend < 0 || key < best_key) {
+                    best_key = key;
+                    best.rend = (i32)r; best.inst = i; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
+                }
+            }
+        }
+    }
+    return best.rend >= 0;
+}
+
+// Object-space image of a world-space hit point, src/rt.rs:782, 798
+struct Obj {
+    const float *R, *I, *X;
+    V3 pos;
+    bool ident;
+    u32 kind;
+};
+MRT_HD Obj obj_of(const Scn &S, const Hit &h)
+{
+    Obj o;
+    o.R = S.F + S.P->off_rend + (u32)h.rend * REND_WORDS;
+    o.I = S.F + S.P->off_inst + h.inst * INST_WORDS;
+    o.X = S.F + S.P->off_xf + ldu(o.I, INST_XF) * XF_WORDS;
+    o.pos = ld3(o.I, INST_POS);
+    o.ident = ldu(o.X, XF_IDENT) != 0;
+    o.kind = ldu(o.R, REND_KIND);
+    return o;
+}
+MRT_HD V3 to_object(const Obj &o, V3 hp) { return add(o.pos, xf_vec(o.X, o.ident, sub(hp, o.pos))); }
+
+// Renderer::normal, src/rt.rs:776-793 with the Normal impls, src/rt.rs:414-466
+MRT_HD V3 hit_normal(const Scn &S, const Obj &o, V3 n_hit, i32 tri_idx)
+{
+    if (o.kind == KIND_PLANE) return ld3(o.I, INST_PLANE_NW);          // norm(R*(L*n)) is per instance
+    V3 n;
+    if (o.kind == KIND_SPHERE) n = sub(n_hit, o.pos);
+    else if (o.kind == KIND_BOX) n = box_normal(ld3(o.R, REND_GEO + 3), n_hit, o.pos);
+    else if (o.kind == KIND_TRIANGLE) n = cross(ld3(o.R, REND_GEO + 3), ld3(o.R, REND_GEO + 6));
+    else {
+        const float *M = S.F + S.P->off_mesh + ldu(o.R, REND_GEO) * MESH_WORDS;
+        const float *T = S.F + S.P->off_tri + (ldu(M, MESH_TRI0) + (u32)tri_idx) * TRI_WORDS;
+        n = cross(ld3(T, 3), ld3(T, 6));
+    }
+    return norm(xf_vec(o.X, o.ident, n));
+}
+
+// Renderer::to_uv, src/rt.rs:795-809 with the UV impls, src/rt.rs:468-542 (triangle / mesh maps are
+// rejected by mrt_create: the reference hits todo!())
+MRT_HD UV hit_uv(const Obj &o, V3 n_hit)
+{
+    UV r;
+    if (o.kind == KIND_SPHERE) {
+        const V3 v = norm(sub(n_hit, o.pos));
+        r.x = 0.5f + 0.5f * atan2_(v.x, -v.y) / kPi;
+        r.y = 0.5f - 0.5f * v.z;
+    } else if (o.kind == KIND_PLANE) {
+        r.x = fract_(n_hit.x + 0.5f);
+        if (r.x < 0.0f) r.x = 1.0f + r.x;
+        r.y = fract_(n_hit.y + 0.5f);
+        if (r.y < 0.0f) r.y = 1.0f + r.y;
+    } else if (o.kind == KIND_BOX) {
+        r = box_uv(ld3(o.R, REND_GEO + 3), n_hit, o.pos);
+    } else {
+        r.x = 0.0f; r.y = 0.0f;
+    }
+    return r;
+}
+
+// RayHit::get_* / Renderer::get_*, src/rt.rs:592-616, 811-863
+struct Surf {
+    const float *M;
+    bool maps;
+    UV uv;
+};
+MRT_HD Surf surf_of(const Scn &S, const Hit &h, const Obj &o, V3 n_hit)
+{
+    Surf s;
+    s.M = S.F + S.P->off_mat + (u32)h.rend * MAT_WORDS;
+    s.maps = (ldu(o.R, REND_FLAGS) & RF_HAS_MAPS) != 0;
+    s.uv.x = 0.0f; s.uv.y = 0.0f;
+    if (s.maps) s.uv = hit_uv(o, n_hit);
+    return s;
+}
+MRT_HD float surf_scalar(const Scn &S, const Surf &s, u32 slot, u32 field)
+{
+    if (s.maps) {
+        const i32 id = (i32)ldu(s.M, MAT_MAP + slot);
+        if (id >= 0) return tex_fetch(S, id, s.uv).x;
+    }
+    return s.M[field];
+}
+MRT_HD V3 surf_color(const Scn &S, const Surf &s)
+{
+    const V3 albedo = ld3(s.M, MAT_ALBEDO);
+    if (s.maps) {
+        const i32 id = (i32)ldu(s.M, MAT_MAP + MAP_TEX);
+        if (id >= 0) return hadam(albedo, tex_fetch(S, id, s.uv));
+    }
+    return albedo;
+}
+
+// RayTracer::rand, src/rt.rs:996-1007
+MRT_HD V3 rand_normal(V3 n, float r, float u1, float u2)
+{
+    const float th = acos_(1.0f - 2.0f * u1);
+    const float phi = u2 * 2.0f * kPi;
+    float sth, cth, sphi, cphi;
+    sincos_(th, sth, cth);
+    sincos_(phi, sphi, cphi);
+    const V3 v = v3(sth * cphi, sth * sphi, cth);
+    return norm(add(n, muls(v, r)));
+}
+
+// Vec3f::refract, src/lin.rs:96-105
+MRT_HD bool refract(V3 d, float eta, V3 n, V3 &out)
+{
+    const float cosv = dot(neg(n), d);
+    const float k = 1.0f - (eta * eta) * (1.0f - cosv * cosv);
+    if (k < 0.0f) return false;
+    out = add(muls(d, eta), muls(n, cosv * eta + sqrt_(k)));
+    return true;
+}
+
+// RayTracer::iter + the pixel-only half of RayTracer::cast, src/rt.rs:937-947, 900-914
+MRT_HD V3 pixel_focus(const Params &P, float cx, float cy)
+{
+    const float uvx = P.aspect * (cx - 0.5f * P.w) / P.w;
+    const float uvy = (cy - 0.5f * P.h) / P.h;
+    const V3 dir = norm(v3(uvx, P.inv2tan, -uvy));
+    const V3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    const V3 orig = add(cam, muls(dir, kE));           // Ray::cast_default
+    return add(orig, muls(dir, P.foc));                // Vec3f::from(&ray) with t = foc
+}
+
+// the per-sample half of RayTracer::cast, src/rt.rs:916-931
+MRT_HD void camera_ray(const Params &P, V3 focus, u32 pk, V3 &o, V3 &d)
+{
+    const float u1 = u32_to_unit(draw_u32(pk, DIM_LENS_X));
+    const float u2 = u32_to_unit(draw_u32(pk, DIM_LENS_Z));
+    const V3 pos = v3(P.cam_pos[0] + (u1 - 0.5f) * P.aprt, P.cam_pos[1], P.cam_pos[2] + (u2 - 0.5f) * P.aprt);
+    const V3 new_dir = norm(sub(focus, pos));
+    d = m3mul(P.cam_R, m3mul(P.cam_L, new_dir));
+    o = add(pos, muls(d, kE));
+}
+
+MRT_HD u32 dim_of(u32 bounce, u32 slot) { return DIM_BOUNCE0 + bounce * DIMS_PER_BOUNCE + slot; }
+
+// All samples of one supersampled pixel: Sampler::execute's per-pixel body, n_samples times
+// (src/sampler.rs:45-70 calling RayTracer::iter / reduce_light, src/rt.rs:937-994, whose iterator
+// is RaytraceIterator::next, src/rt.rs:1014-1066).  acc is the running colors[(x, y)] entry.
+MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
+{
+    const Params &P = *S.P;
+    const u32 pixel = y * P.nw + x;
+    const V3 focus = pixel_focus(P, (float)x, (float)y);
+    const V3 sky_init = v3(P.sky_init[0], P.sky_init[1], P.sky_init[2]);
+
+    u32 s = 0;
+    bool fresh = true;
+    u32 pk = 0, b = 0;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
+    V3 T = v3(1, 1, 1), L = v3(0, 0, 0);
+    float pwr = 1.0f;
+    u32 seg = 0;
+
+    for (;;) {
+        if (fresh) {
+            if (s >= P.n_samples) break;
+            pk = path_key(P.seed_lo, P.seed_hi, pixel, P.sample_base + s);
+            camera_ray(P, focus, pk, o, d);
+            T = v3(1.0f, 1.0f, 1.0f); L = v3(0.0f, 0.0f, 0.0f);
+            pwr = 1.0f; b = 0;
+            fresh = false;
+        }
+        // ---- RaytraceIterator::next ----
+        const RayPre ray = ray_pre(o, d);
+        Hit h;
+        ++seg;
+        if (!trace<false>(S, ray, h)) {
+            // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
+            const V3 c = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
+            acc = add(acc, c);
+            ++s; fresh = true;
+            continue;
+        }
+        const Obj ob = obj_of(S, h);
+        const V3 p0 = add(o, muls(d, h.t0));                       // Vec3f::from(&hit.0.ray)
+        const V3 nh0 = to_object(ob, p0);
+        const Surf sf0 = surf_of(S, h, ob, nh0);
+        const float opacity0 = surf_scalar(S, sf0, MAP_OPACITY, MAT_OPACITY);
+        const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
+
+        // 15 % / opacity coin and refraction from the exit hit, src/rt.rs:1051-1059
+        bool refracted = false;
+        V3 nd = v3(0, 0, 0), np = p0;      // next ray direction / the point it leaves from
+        V3 hp = p0, hn = v3(0, 0, 0);      // recorded hit (n_hit): point and normal
+        Surf sfh = sf0;
+        if (bernoulli(fmin_(1.0f - opacity0, 0.85f), draw_u32(pk, dim_of(b, SL_OPAC_COIN)))) {
+            const V3 p1 = add(o, muls(d, h.t1));
+            const V3 nh1 = to_object(ob, p1);
+            const V3 n1 = hit_normal(S, ob, nh1, h.i1);
+            const Surf sf1 = surf_of(S, h, ob, nh1);
+            float rough = surf_scalar(S, sf1, MAP_ROUGH, MAT_ROUGH);      // Ray::refract, src/rt.rs:574-589
+            const float opac1 = surf_scalar(S, sf1, MAP_OPACITY, MAT_OPACITY);
+            if (metal_c == 0.0f && opac1 != 0.0f && bernoulli(0.80f, draw_u32(pk, dim_of(b, SL_REFR_COIN)))) rough = 1.0f;
+            const V3 nn = rand_normal(n1, rough, u32_to_unit(draw_u32(pk, dim_of(b, SL_REFR_U1))), u32_to_unit(draw_u32(pk, dim_of(b, SL_REFR_U2))));
+            const float eta = 1.0f + 0.5f * surf_scalar(S, sf1, MAP_GLASS, MAT_GLASS);
+            V3 rdir;
+            if (refract(d, eta, nn, rdir)) {
+                refracted = true;
+                nd = norm(rdir); np = p1;
+                hp = p1; hn = n1; sfh = sf1;
+            }
+        }
+        if (!refracted) hn = hit_normal(S, ob, nh0, h.i0);
+        const V3 n0 = hn;   // when not refracted this is hit0's normal (used by reflect below)
+
+        // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
+        const V3 color = surf_color(S, sfh);
+        const float emit = surf_scalar(S, sfh, MAP_EMIT, MAT_EMIT);
+        if (bernoulli(emit, draw_u32(pk, dim_of(b, SL_EMIT_COIN)))) {
+            acc = add(acc, add(L, hadam(T, color)));
+            ++s; fresh = true;
+            continue;
+        }
+
+        // direct light, visibility from hit0 (src/rt.rs:1027-1046), shading at the recorded hit (:973-987)
+        V3 l_col = v3(0.0f, 0.0f, 0.0f);
+        if (P.n_light) {
+            const float rough_h = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);
+            const float metal_h = surf_scalar(S, sfh, MAP_METAL, MAT_METAL);
+            for (u32 li = 0; li < P.n_light; ++li) {
+                const float *Lt = S.F + P.off_light + li * LIGHT_WORDS;
+                const bool point = ldu(Lt, LIGHT_KIND) == LK_POINT;
+                const V3 lv = ld3(Lt, LIGHT_V);
+                const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
+                const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
+                Hit hs;
+                if (trace<true>(S, ray_pre(so, ls), hs)) continue;
+                const V3 ln = point ? norm(sub(lv, hp)) : lv;             // l.norm() at the recorded hit
+                const float diff = fmax_(dot(ln, hn), 0.0f);
+                const float sp = fmax_(dot(d, reflect(ln, hn)), 0.0f);
+                const float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16;   // powi(32)
+                const float spec = s32 * (1.0f - rough_h);
+                const V3 o_col = muls(color, 1.0f - metal_h);
+                V3 t = hadam(muls(o_col, diff), ld3(Lt, LIGHT_COLOR));
+                t = v3(t.x + spec, t.y + spec, t.z + spec);
+                l_col = add(l_col, muls(t, Lt[LIGHT_PWR]));
+            }
+        }
+
+        // Ray::reflect at hit0, src/rt.rs:559-572 (skipped when the refracted ray replaced it)
+        if (!refracted) {
+            float rough = surf_scalar(S, sf0, MAP_ROUGH, MAT_ROUGH);
+            if (metal_c == 0.0f && opacity0 != 0.0f && bernoulli(0.80f, draw_u32(pk, dim_of(b, SL_REFL_COIN)))) rough = 1.0f;
+            const V3 nn = rand_normal(n0, rough, u32_to_unit(draw_u32(pk, dim_of(b, SL_REFL_U1))), u32_to_unit(draw_u32(pk, dim_of(b, SL_REFL_U2))));
+            nd = norm(reflect(d, nn));
+        }
+
+        // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
+        L = add(L, hadam(T, muls(l_col, pwr)));
+        T = hadam(T, muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr));
+
+        // Ray::cast, src/rt.rs:551-553, 571
+        o = add(np, muls(nd, kE));
+        d = nd;
+        pwr = pwr * P.q;
+        ++b;
+        if (b > P.bounce) {          // src/rt.rs:1018
+            acc = add(acc, add(L, hadam(T, sky_init)));
+            ++s; fresh = true;
+        }
+    }
+    segments = seg;
+}
+
+}  // namespace mrt

@@ -1,0 +1,161 @@
+"""Python mirror of the reference's `Sampler` (src/sampler.rs:11-100) over the C ABI.
+
+Same three entry points, same meaning:
+    Sampler(workers, n_dim)              Sampler::new      (src/sampler.rs:19)
+    execute(scene, frame, rt) -> secs    Sampler::execute  (src/sampler.rs:28)   one sample pass
+    img(frame) -> uint8 [h][w][3]        Sampler::img      (src/sampler.rs:80)
+`workers` / `n_dim` (the thread-pool size and tile grid of the CPU implementation) have no
+meaning on the GPU and are accepted for signature compatibility only.  The context is created
+lazily on the first execute, because the scene and frame only arrive then, exactly as the
+Rust shim in INTEGRATION.md does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, _lib
+from .scene import Render
+
+
+class Sampler:
+    def __init__(self, workers: int = 24, n_dim: int = 64, *, seed: int = 1, device: int = -1,
+                 shard_index: int = 0, shard_count: int = 1, shard_rows: int = 8):
+        self.workers, self.n_dim = workers, n_dim
+        self.seed, self.device = seed, device
+        self.shard_index, self.shard_count, self.shard_rows = shard_index, shard_count, shard_rows
+        self._ctx = None
+        self._holder = None
+        self._key = None
+        self.nw = self.nh = self.local_rows = 0
+        self.res = (0, 0)
+
+    # -- context -----------------------------------------------------------------------------
+    def _ensure(self, render: Render):
+        key = id(render)
+        if self._ctx is not None and key == self._key:
+            return
+        self.close()
+        L = _lib.lib()
+        self._holder = _abi.build_desc(render)
+        opts = _abi.Opts()
+        opts.abi_version = _abi.ABI_VERSION
+        opts.seed = self.seed
+        opts.device = self.device
+        opts.shard_index, opts.shard_count, opts.shard_rows = self.shard_index, self.shard_count, self.shard_rows
+        ctx = L.mrt_create(C.cast(self._holder.ptr(), C.c_void_p), C.byref(opts))
+        if not ctx:
+            raise _lib.MrtError(L.mrt_last_status(), L.mrt_last_error().decode())
+        self._ctx, self._key = ctx, key
+        nw, nh, lr = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(L.mrt_dims(ctx, C.byref(nw), C.byref(nh), C.byref(lr)))
+        self.nw, self.nh, self.local_rows = nw.value, nh.value, lr.value
+        self.res = tuple(render.frame.res)
+
+    def close(self):
+        if self._ctx is not None:
+            _lib.lib().mrt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the reference's API -----------------------------------------------------------------
+    def execute(self, scene_or_render, frame=None, rt=None, n_samples: int = 1) -> float:
+        """One Sampler::execute pass (n_samples > 1: that many consecutive passes in one launch).
+
+        Accepts either a whole Render, or (scene, frame, rt) like the reference."""
+        render = scene_or_render if isinstance(scene_or_render, Render) else Render(rt=rt, frame=frame, scene=scene_or_render)
+        if not isinstance(scene_or_render, Render):
+            # keep one Render object per (scene, frame, rt) triple so the context is reused across passes
+            k = (id(scene_or_render), id(frame), id(rt))
+            if getattr(self, "_triple_key", None) == k:
+                render = self._triple_render
+            else:
+                self._triple_key, self._triple_render = k, render
+        self._ensure(render)
+        secs = C.c_double()
+        _lib.check(_lib.lib().mrt_execute(self._ctx, n_samples, C.byref(secs)))
+        return secs.value
+
+    def img(self, frame=None) -> np.ndarray:
+        self._need()
+        out = np.empty((self.res[1], self.res[0], 3), np.uint8)
+        _lib.check(_lib.lib().mrt_img(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    # -- extras of the C ABI -----------------------------------------------------------------
+    def _need(self):
+        if self._ctx is None:
+            raise _lib.MrtError(_abi.MRT_ERR_STATE, "no context: call execute() first")
+
+    def img_ss(self) -> np.ndarray:
+        self._need()
+        out = np.empty((self.nh, self.nw, 3), np.uint8)
+        _lib.check(_lib.lib().mrt_img_ss(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def accum(self):
+        """(colors, last_count): full-frame f32 sums [nh][nw][3] (rows of other shards are zero)."""
+        self._need()
+        out = np.zeros((self.nh, self.nw, 3), np.float32)
+        cnt = C.c_uint32()
+        _lib.check(_lib.lib().mrt_accum(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(cnt)))
+        return out, cnt.value
+
+    def accum_local(self):
+        self._need()
+        out = np.zeros((self.local_rows, self.nw, 3), np.float32)
+        rows = np.zeros(self.local_rows, np.uint32)
+        _lib.check(_lib.lib().mrt_accum_local(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                              rows.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out, rows
+
+    def accum_device_ptr(self):
+        self._need()
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(_lib.lib().mrt_accum_device_ptr(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_accum(self, rgb, count):
+        self._need()
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        if rgb.shape != (self.nh, self.nw, 3):
+            raise ValueError(f"expected {(self.nh, self.nw, 3)}, got {rgb.shape}")
+        _lib.check(_lib.lib().mrt_set_accum(self._ctx, rgb.ctypes.data_as(C.POINTER(C.c_float)), int(count)))
+
+    def reset(self):
+        self._need()
+        _lib.check(_lib.lib().mrt_reset(self._ctx))
+
+    def stats(self) -> dict:
+        self._need()
+        st = _abi.Stats()
+        _lib.check(_lib.lib().mrt_get_stats(self._ctx, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+
+def raytrace(render: Render, *, seed=1, update=None, batch=None, **kw):
+    """CLI::raytrace / HttpServer::raytrace (src/cli.rs:155-177, src/http.rs:136-148): the per-sample loop
+    followed by img().  `update(sample_index, image)` mirrors --update; `batch` fuses that many passes
+    into one launch when no per-sample image is needed."""
+    s = Sampler(kw.pop("workers", 24), kw.pop("n_dim", 64), seed=seed, **kw)
+    n = render.rt.sample
+    if update is None:
+        step = batch or n
+        done = 0
+        while done < n:
+            k = min(step, n - done)
+            s.execute(render, n_samples=k)
+            done += k
+    else:
+        for i in range(n):
+            s.execute(render)
+            update(i, s.img())
+    out = s.img()
+    s.close()
+    return out

@@ -52,9 +52,22 @@ static inline v3 v3_recip(v3 a) { return V3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
 static inline v3 v3_abs(v3 a) { return V3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }         /* lin.rs:80-86 */
 static inline v4 v4_neg(v4 a) { v4 r = {-a.w, -a.x, -a.y, -a.z}; return r; }             /* lin.rs:445-456 */
 
-/* f32::max / f32::min (maxnum / minnum: a NaN operand yields the other one) */
-static inline float f_max(float a, float b) { if (a != a) return b; if (b != b) return a; return a < b ? b : a; }
-static inline float f_min(float a, float b) { if (a != a) return b; if (b != b) return a; return b < a ? b : a; }
+/* f32::max / f32::min (maxNum / minNum): a NaN operand yields the other one.  IEEE leaves the
+ * result for a (+0, -0) pair open; the contract fixes max -> +0, min -> -0. */
+static inline float f_max(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return (om_f2u(a) & 0x80000000u) ? b : a;
+    return a < b ? b : a;
+}
+static inline float f_min(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return (om_f2u(a) & 0x80000000u) ? a : b;
+    return b < a ? b : a;
+}
 
 /* Vec3f::refract, lin.rs:96-105 */
 static inline int v3_refract(v3 d, float eta, v3 n, v3 *out)

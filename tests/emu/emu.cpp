@@ -1,0 +1,167 @@
+// emu.cpp — TEST INFRASTRUCTURE ONLY.  Compiles the device headers of the HIP kernels
+// (mrt_trace.h, mrt_post.h, mrt_math.h) and the host packer for x86 so that `-m "not gpu"` tests
+// can check the kernel's per-lane logic and the packed scene layout against the CPU oracle
+// without a GPU.  Nothing in the product loads this library; libmrt_hip.so has no CPU path.
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+#include <atomic>
+
+#include "../../micro_raytracer_amd/csrc/mrt_pack.h"
+#include "../../micro_raytracer_amd/csrc/mrt_post.h"
+#include "../../micro_raytracer_amd/csrc/mrt_trace.h"
+
+using namespace mrt;
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *emu_error(void) { return g_err.c_str(); }
+
+// pack only: returns code, fills sizes (blob words, nw, nh)
+int emu_pack(const mrt_render_desc *d, uint32_t *blob_words, uint32_t *nw, uint32_t *nh, uint32_t *info /*[8]*/)
+{
+    Packed pk;
+    const int rc = pack_scene(d, pk, g_err);
+    if (rc) return rc;
+    if (blob_words) *blob_words = pk.P.blob_words;
+    if (nw) *nw = pk.nw;
+    if (nh) *nh = pk.nh;
+    if (info) { info[0] = pk.n_tex_u8; info[1] = pk.n_tex_f32; info[2] = pk.n_nodes; info[3] = pk.n_leaf_ids; info[4] = pk.n_tris; info[5] = pk.n_xf; info[6] = pk.P.n_inst; info[7] = pk.P.n_rend; }
+    return 0;
+}
+
+// the megakernel's per-lane body over every pixel of rows [row0,row1) (frame rows), accumulating into accum[nh][nw][3]
+int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, uint32_t n_samples, uint32_t row0, uint32_t row1,
+               uint32_t threads, float *accum, uint64_t *segments)
+{
+    Packed pk;
+    const int rc = pack_scene(d, pk, g_err);
+    if (rc) return rc;
+    Params P = pk.P;
+    P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
+    P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32);
+    P.n_samples = n_samples; P.sample_base = sample_base;
+    if (row1 > pk.nh) row1 = pk.nh;
+    Scn S;
+    S.F = reinterpret_cast<const float *>(pk.blob.data());
+    S.P = &P;
+    std::atomic<uint32_t> next(row0);
+    std::atomic<uint64_t> segs(0);
+    if (threads == 0) threads = 1;
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < threads; ++t) pool.emplace_back([&]() {
+        uint64_t local = 0;
+        for (;;) {
+            const uint32_t y = next.fetch_add(1);
+            if (y >= row1) break;
+            for (uint32_t x = 0; x < pk.nw; ++x) {
+                float *px = accum + ((size_t)y * pk.nw + x) * 3;
+                V3 acc = v3(px[0], px[1], px[2]);
+                u32 sg = 0;
+                render_pixel(S, x, y, acc, sg);
+                px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
+                local += sg;
+            }
+        }
+        segs += local;
+    });
+    for (auto &th : pool) th.join();
+    if (segments) *segments = segs.load();
+    return 0;
+}
+
+// Sampler::img through the kernels' per-element bodies
+int emu_img(const mrt_render_desc *d, const float *accum, uint32_t count, uint8_t *out_ss, uint8_t *out)
+{
+    Packed pk;
+    const int rc = pack_scene(d, pk, g_err);
+    if (rc) return rc;
+    const u32 nw = pk.nw, nh = pk.nh, rw = pk.res_w, rh = pk.res_h;
+    const float rcnt = 1.0f / (float)count;
+    const float wexp = (1.0f - pk.exp) * (1.0f - pk.exp);
+    std::vector<uint8_t> ss((size_t)nw * nh * 3);
+    for (size_t i = 0; i < ss.size(); ++i) ss[i] = tonemap_channel(accum[i], rcnt, pk.gamma, wexp);
+    if (out_ss) memcpy(out_ss, ss.data(), ss.size());
+    if (!out) return 0;
+    if (rw == nw && rh == nh) { memcpy(out, ss.data(), ss.size()); return 0; }
+    ResampleTaps v, h;
+    lanczos3_taps(nh, rh, v);
+    lanczos3_taps(nw, rw, h);
+    std::vector<float> tmp((size_t)nw * rh * 3);
+    for (u32 oy = 0; oy < rh; ++oy)
+        for (u32 e = 0; e < nw * 3; ++e) {
+            float t = 0.0f;
+            for (u32 i = 0; i < v.count[oy]; ++i) t += (float)ss[(size_t)(v.left[oy] + i) * nw * 3 + e] * v.weight[(size_t)oy * v.cap + i];
+            tmp[(size_t)oy * nw * 3 + e] = t;
+        }
+    for (u32 y = 0; y < rh; ++y)
+        for (u32 ox = 0; ox < rw; ++ox) {
+            float t[3] = {0.0f, 0.0f, 0.0f};
+            for (u32 i = 0; i < h.count[ox]; ++i) {
+                const float *p = tmp.data() + ((size_t)y * nw + (h.left[ox] + i)) * 3;
+                const float w = h.weight[(size_t)ox * h.cap + i];
+                t[0] += p[0] * w; t[1] += p[1] * w; t[2] += p[2] * w;
+            }
+            for (int k = 0; k < 3; ++k) out[((size_t)y * rw + ox) * 3 + k] = resample_to_u8(t[k]);
+        }
+    return 0;
+}
+
+void emu_math(int op, const float *a, const float *b, float *out, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const float x = a[i], y = b ? b[i] : 0.0f;
+        float s, c, r = 0.0f;
+        switch (op) {
+        case 0: sincos_(x, s, c); r = s; break;
+        case 1: sincos_(x, s, c); r = c; break;
+        case 2: r = acos_(x); break;
+        case 3: r = atan2_(x, y); break;
+        case 4: r = pow_(x, y); break;
+        case 5: r = 1.0f / x; break;
+        case 6: r = sqrt_(x); break;
+        case 7: r = x / y; break;
+        case 8: r = fmax_(x, y); break;
+        case 9: r = fmin_(x, y); break;
+        case 10: r = u2f((u32)total_key(x)); break;
+        case 11: r = u32_to_unit(draw_u32(f2u(x), f2u(y))); break;
+        case 12: r = norm(v3(x, y, 0.25f)).x; break;
+        default: break;
+        }
+        out[i] = r;
+    }
+}
+
+// leaves of mesh renderer `mesh_index`-th mesh in traversal order, to compare the packer's octree with the oracle's
+int emu_octree(const float *tris, uint32_t n_tris, float *leaf_boxes, uint32_t *leaf_counts, uint32_t *ids, uint32_t cap, uint32_t *n_ids)
+{
+    OctreeFlat oc;
+    build_octree(tris, n_tris, oc);
+    if (oc.root == NO_NODE) return oc.empty_root ? -2 : -1;
+    uint32_t nl = 0, ni = 0;
+    // DFS in child order
+    std::vector<uint32_t> stack = {oc.root};
+    while (!stack.empty()) {
+        const uint32_t n = stack.back(); stack.pop_back();
+        const float *q = oc.nodes.data() + (size_t)n * NODE_WORDS;
+        const uint32_t first = f2u(q[NODE_FIRST]), cnt = f2u(q[NODE_COUNT]);
+        if (cnt & 0x80000000u) {
+            const uint32_t c = cnt & 0x7fffffffu;
+            if (leaf_boxes) { float *b = leaf_boxes + (size_t)nl * 6; b[0] = q[NODE_REL]; b[1] = q[NODE_REL + 1]; b[2] = q[NODE_REL + 2]; b[3] = 2.0f * q[NODE_HALF]; b[4] = 2.0f * q[NODE_HALF + 1]; b[5] = 2.0f * q[NODE_HALF + 2]; }
+            if (leaf_counts) leaf_counts[nl] = c;
+            for (uint32_t i = 0; i < c; ++i) { if (ids && ni < cap) ids[ni] = oc.leaf_ids[first + i]; ++ni; }
+            ++nl;
+        } else {
+            for (uint32_t i = cnt; i-- > 0;) stack.push_back(first + i);
+        }
+    }
+    if (n_ids) *n_ids = ni;
+    return (int)nl;
+}
+
+}  // extern "C"
