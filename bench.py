@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the path-tracing hot path on N MI355X (one process per GPU, RCCL).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Step = one pass of the hot path over one batch: every supersampled pixel of the frame gets `spp`
+more path samples (mrt_execute, i.e. `spp` consecutive Sampler::execute passes of the reference,
+src/sampler.rs:28-78) and, for N > 1, the one RCCL gather of the shard accumulators to rank 0.
+Inputs (the packed scene, the accumulators) are resident in HBM before the timed region.
+
+Workload (BASELINE.json north_star headline): Cornell box (example/CornellBox.json geometry), 1920x1080,
+1024 spp, 8 bounces, rows sharded over the N GPUs (strong scaling: the frame is fixed as N grows).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TFLOPS = 157.3       # FP32 vector peak (FMA = 2 flop); 78.6 without fusion, which the math contract forbids
+FLOP_PER_SEGMENT = 400.0       # SURVEY.md §8d algorithmic estimate for the Cornell box (10 primitives)
+
+WORKLOADS = {
+    # name: (builder kwargs, spp per step)
+    "cornell_1080p_1024spp_b8": (dict(kind="cornell_box", res=(1920, 1080), bounce=8), 1024),
+    "cornell_512_64spp_b8": (dict(kind="cornell_box", res=(512, 512), bounce=8), 64),           # BASELINE.json configs[1]
+    "cornell2_4k_64spp_b16": (dict(kind="cornell_box2", res=(1920, 1080), ssaa=2, bounce=16), 64),  # configs[2] geometry
+}
+
+
+def build_render(spec, spp):
+    from micro_raytracer_amd import load_render, scenes
+    spec = dict(spec)
+    kind = spec.pop("kind")
+    return load_render(getattr(scenes, kind)(sample=spp, **spec))
+
+
+def cpu_baseline(render, seconds_target=15.0):
+    """The CPU oracle (a C restatement of the reference's algorithm, kind "port": the Rust reference
+    cannot be built here) timed on this host's cores on a bounded sample of the same workload."""
+    from micro_raytracer_amd import _abi
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    h = _abi.build_desc(render)
+    o = oracle.Oracle(h, seed=1)
+    nh, nw = o.nh, o.nw
+    rows = (nh // 2 - 32, nh // 2 + 32)     # 64 rows through the middle of the frame
+    spp = 1
+    t = o.execute(spp, threads=cores, rows=rows)       # calibration pass
+    rate = (rows[1] - rows[0]) * nw * spp / t
+    spp2 = max(1, min(64, int(seconds_target * rate / ((rows[1] - rows[0]) * nw))))
+    t2 = o.execute(spp2, threads=cores, rows=rows)
+    n = (rows[1] - rows[0]) * nw * spp2
+    o.close()
+    return {"value": n / t2 / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"rows {rows[0]}..{rows[1]} of the {nw}x{nh} frame, {spp2} spp, {t2:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell_1080p_1024spp_b8", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the backend has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from micro_raytracer_amd.dist import ShardedSampler
+
+    spec, spp = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    render = build_render(spec, spp)
+    ss = ShardedSampler(render, rank, world, local_rank, seed=1)
+    nw, nh = ss.nw, ss.nh
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ss.execute(spp)
+    sync()
+    kernel_ms, segments = [], 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ss.execute(spp)
+        st = ss.s.stats()
+        kernel_ms.append(st["kernel_ms"])
+        segments += st["segments"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        seg_t = torch.tensor([float(segments)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
+        total_segments = float(seg_t.item())
+    else:
+        total_segments = float(segments)
+
+    if rank == 0:
+        st = ss.s.stats()
+        samples = float(nw) * nh * spp * args.steps
+        # roofline of the dominant kernel (pt_megakernel) on this rank: algorithmic HBM bytes per launch
+        # = accumulator read + write (12 B + 12 B per owned pixel) + one read of the packed scene
+        px_local = ss.s.local_rows * nw
+        alg_bytes = 24.0 * px_local + st["scene_bytes"]
+        k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        seg_local = segments / max(1, args.steps)
+        valu_tflops = seg_local * FLOP_PER_SEGMENT / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        line = {
+            "metric": "Msamples/sec (res x spp)", "value": samples / elapsed / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene": "Cornell box (5 planes + 5 spheres, App. B.2 of SURVEY.md)",
+                       "res": [render.frame.res[0], render.frame.res[1]], "ssaa": render.frame.ssaa, "spp_per_step": spp,
+                       "bounce": render.rt.bounce, "samples_per_step": float(nw) * nh * spp,
+                       "sharding": f"rows, block-cyclic x{ss.shard_rows}, {world} rank(s), 1 RCCL gather/step" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "pt_megakernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "by construction not HBM-bound (SURVEY.md §8d): the scene lives in LDS, HBM sees 24 B per pixel per launch"},
+            "valu": {"achieved_tflops": valu_tflops, "peak_tflops": VALU_PEAK_TFLOPS, "frac": valu_tflops / VALU_PEAK_TFLOPS,
+                     "segments_per_sample": total_segments / samples, "flop_per_segment_model": FLOP_PER_SEGMENT,
+                     "Gsegments_per_s": total_segments / elapsed / 1e9},
+            "kernel": {"block_threads": st["block_threads"], "lds_bytes": st["lds_bytes"], "scene_bytes": st["scene_bytes"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(render)
+        print(json.dumps(line), flush=True)
+    ss.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -200,6 +200,18 @@ int mrt_accum_local(mrt_ctx *ctx, float *rgb, uint32_t *rows);
  * hand-off to a collective (one RCCL gather of these per mrt_execute batch). */
 int mrt_accum_device_ptr(mrt_ctx *ctx, void **dev_ptr, size_t *bytes);
 
+/* Rows the shard-local accumulator is allocated for: the largest local_rows over all shards of this
+ * shard_count (so that equal-sized buffers can be gathered); rows past local_rows stay zero. */
+int mrt_padded_rows(const mrt_ctx *ctx, uint32_t *rows);
+
+/* Use caller-owned device memory (e.g. a torch tensor) of at least padded_rows * nw * 3 floats as the
+ * shard-local accumulator from now on; current contents are copied over.  The buffer must outlive the
+ * context or a later mrt_bind_accum(ctx, NULL, 0), which switches back to library-owned memory. */
+int mrt_bind_accum(mrt_ctx *ctx, void *dev_ptr, size_t bytes);
+
+/* mrt_set_accum from device memory on this context's device (e.g. the frame assembled from a gather). */
+int mrt_set_accum_device(mrt_ctx *ctx, const void *dev_rgb, uint32_t count);
+
 /* Replace the accumulator contents with a full frame (rgb[nh][nw][3]) and sample count,
  * e.g. on rank 0 after a gather, or to resume (the reference never persists `colors`). */
 int mrt_set_accum(mrt_ctx *ctx, const float *rgb, uint32_t count);

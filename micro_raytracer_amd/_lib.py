@@ -13,7 +13,8 @@ _LIB = None
 SYMBOLS = (
     "mrt_create", "mrt_destroy", "mrt_execute", "mrt_dims", "mrt_accum", "mrt_accum_local", "mrt_accum_device_ptr",
     "mrt_set_accum", "mrt_img", "mrt_img_ss", "mrt_reset", "mrt_get_stats", "mrt_last_error", "mrt_last_status",
-    "mrt_abi_version", "mrt_device_count", "mrt_selftest_math",
+    "mrt_abi_version", "mrt_device_count", "mrt_selftest_math", "mrt_padded_rows", "mrt_bind_accum",
+    "mrt_set_accum_device",
 )
 
 
@@ -63,6 +64,9 @@ def lib():
     L.mrt_last_status.restype = C.c_int
     L.mrt_abi_version.restype = u32
     L.mrt_device_count.restype = C.c_int
+    L.mrt_padded_rows.argtypes = [vp, u32p]
+    L.mrt_bind_accum.argtypes = [vp, vp, C.c_size_t]
+    L.mrt_set_accum_device.argtypes = [vp, vp, u32]
     L.mrt_selftest_math.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p, C.c_size_t]
     _LIB = L
     return L

@@ -52,7 +52,9 @@ struct mrt_ctx {
     Packed pk;
     Params P;
     u32 *d_blob = nullptr;
-    float *d_accum = nullptr;            // [local_rows][nw][3]
+    float *d_accum = nullptr;            // [padded_rows][nw][3], rows past local_rows stay zero
+    float *d_accum_own = nullptr;        // library-owned allocation (d_accum may point to caller memory)
+    u32 padded_rows = 0;
     unsigned long long *d_segments = nullptr;
     u32 count = 0;                       // Sampler.last_count
     uint64_t seed = 0;
@@ -84,7 +86,7 @@ void free_ctx(mrt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->d_blob, c->d_accum, c->d_segments, c->d_full, c->d_ss, c->d_out, c->d_tmp, c->d_vl, c->d_vc, c->d_hl, c->d_hc, c->d_vw, c->d_hw};
+    void *ptrs[] = {c->d_blob, c->d_accum_own, c->d_segments, c->d_full, c->d_ss, c->d_out, c->d_tmp, c->d_vl, c->d_vc, c->d_hl, c->d_hc, c->d_vw, c->d_hw};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -149,8 +151,14 @@ mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
     const size_t blob_bytes = (size_t)c->pk.blob.size() * 4;
     if ((e = hipMalloc((void **)&c->d_blob, blob_bytes ? blob_bytes : 16)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
     if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), blob_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
-    const size_t acc_bytes = (size_t)(c->local_rows ? c->local_rows : 1) * nw * 3 * sizeof(float);
-    if ((e = hipMalloc((void **)&c->d_accum, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(accumulator)", e);
+    {
+        const u32 n_blocks = (nh + c->shard_rows - 1) / c->shard_rows;
+        c->padded_rows = ((n_blocks + shard_count - 1) / shard_count) * c->shard_rows;
+        if (shard_count == 1) c->padded_rows = nh;
+    }
+    const size_t acc_bytes = (size_t)c->padded_rows * nw * 3 * sizeof(float);
+    if ((e = hipMalloc((void **)&c->d_accum_own, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(accumulator)", e);
+    c->d_accum = c->d_accum_own;
     if ((e = hipMemset(c->d_accum, 0, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
     if ((e = hipMalloc((void **)&c->d_segments, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);
     if ((e = hipMemset(c->d_segments, 0, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
@@ -254,7 +262,50 @@ int mrt_accum_device_ptr(mrt_ctx *c, void **dev_ptr, size_t *bytes)
 {
     if (!c) return fail(MRT_ERR_ARG, "mrt_accum_device_ptr: null context");
     if (dev_ptr) *dev_ptr = c->d_accum;
-    if (bytes) *bytes = (size_t)c->local_rows * c->pk.nw * 3 * sizeof(float);
+    if (bytes) *bytes = (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float);
+    ok();
+    return MRT_OK;
+}
+
+int mrt_padded_rows(const mrt_ctx *c, uint32_t *rows)
+{
+    if (!c || !rows) return fail(MRT_ERR_ARG, "mrt_padded_rows: null argument");
+    *rows = c->padded_rows;
+    ok();
+    return MRT_OK;
+}
+
+int mrt_bind_accum(mrt_ctx *c, void *dev_ptr, size_t bytes)
+{
+    if (!c) return fail(MRT_ERR_ARG, "mrt_bind_accum: null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t need = (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float);
+    float *dst = dev_ptr ? (float *)dev_ptr : c->d_accum_own;
+    if (dev_ptr && bytes < need) return fail(MRT_ERR_ARG, "mrt_bind_accum: buffer of %zu bytes, need %zu", bytes, need);
+    if (dst != c->d_accum) {
+        HIP_TRY(hipMemcpy(dst, c->d_accum, need, hipMemcpyDeviceToDevice));
+        c->d_accum = dst;
+        c->P.accum = dst;
+    }
+    ok();
+    return MRT_OK;
+}
+
+int mrt_set_accum_device(mrt_ctx *c, const void *dev_rgb, uint32_t count)
+{
+    if (!c || !dev_rgb) return fail(MRT_ERR_ARG, "mrt_set_accum_device: null argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->pk.nw * c->pk.nh * 3 * sizeof(float);
+    if (c->shard_count == 1) {
+        HIP_TRY(hipMemcpy(c->d_accum, dev_rgb, bytes, hipMemcpyDeviceToDevice));
+        c->count = count;
+    } else {
+        if (!c->d_full) HIP_TRY(hipMalloc((void **)&c->d_full, bytes));
+        HIP_TRY(hipMemcpy(c->d_full, dev_rgb, bytes, hipMemcpyDeviceToDevice));
+        c->full_count = count;
+    }
     ok();
     return MRT_OK;
 }
@@ -283,7 +334,7 @@ int mrt_reset(mrt_ctx *c)
     if (!c) return fail(MRT_ERR_ARG, "mrt_reset: null context");
     int rc = set_device(c);
     if (rc) return rc;
-    HIP_TRY(hipMemset(c->d_accum, 0, (size_t)(c->local_rows ? c->local_rows : 1) * c->pk.nw * 3 * sizeof(float)));
+    HIP_TRY(hipMemset(c->d_accum, 0, (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float)));
     if (c->d_full) { (void)hipFree(c->d_full); c->d_full = nullptr; }
     c->count = 0; c->full_count = 0;
     ok();

@@ -1,0 +1,95 @@
+"""Multi-GPU row sharding: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The reference merges per-tile results into one HashMap under a Mutex (src/sampler.rs:60-70).
+Here every rank owns the supersampled rows of a block-cyclic set of 8-row blocks
+(block b -> rank b % world), renders them into its own accumulator, and ONE gather per
+batch of samples moves the shard accumulators to rank 0 over xGMI.  Nothing is reduced:
+shards are disjoint, so a ring all-reduce (per-link bound on the xGMI mesh) would only add
+traffic; a gather uses the 7 inbound links of rank 0 concurrently.
+
+Everything here is plumbing over torch tensors; it runs unchanged on CPU tensors with the
+gloo backend (tests/test_dist_gloo.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+DEFAULT_SHARD_ROWS = 8
+
+
+def shard_row_index(nh: int, rank: int, world: int, shard_rows: int = DEFAULT_SHARD_ROWS) -> np.ndarray:
+    """Frame rows owned by `rank`, in local order (same rule as mrt_create, csrc/mrt_api.cpp)."""
+    y = np.arange(nh)
+    return y[(y // shard_rows) % world == rank].astype(np.int64)
+
+
+def padded_rows(nh: int, world: int, shard_rows: int = DEFAULT_SHARD_ROWS) -> int:
+    """Rows every shard buffer is allocated for (the largest shard), so gathers are equal-sized."""
+    if world == 1:
+        return nh
+    n_blocks = (nh + shard_rows - 1) // shard_rows
+    return ((n_blocks + world - 1) // world) * shard_rows
+
+
+def gather_frame(local, nh: int, nw: int, shard_rows: int = DEFAULT_SHARD_ROWS, dst: int = 0, group=None, out=None):
+    """Gather shard accumulators ([padded_rows, nw, 3] f32 tensors, one per rank) to rank `dst` and
+    place their rows into the full frame [nh, nw, 3].  Returns the frame on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    pr = padded_rows(nh, world, shard_rows)
+    assert tuple(local.shape) == (pr, nw, 3), (tuple(local.shape), (pr, nw, 3))
+    if world == 1:
+        return local[:nh]
+    if rank == dst:
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.gather(local, gather_list=parts, dst=dst, group=group)
+        frame = out if out is not None else torch.empty((nh, nw, 3), dtype=local.dtype, device=local.device)
+        for r, part in enumerate(parts):
+            rows = torch.from_numpy(shard_row_index(nh, r, world, shard_rows)).to(local.device)
+            frame.index_copy_(0, rows, part[: rows.numel()])
+        return frame
+    dist.gather(local, gather_list=None, dst=dst, group=group)
+    return None
+
+
+class ShardedSampler:
+    """Sampler for rank `rank` of `world` GPUs: execute() renders this rank's rows and gathers the frame
+    on rank 0; img() is served by rank 0 (Sampler::img needs every row)."""
+
+    def __init__(self, render, rank: int, world: int, device: int, seed: int = 1, shard_rows: int = DEFAULT_SHARD_ROWS):
+        import torch
+        from .sampler import Sampler
+
+        self.rank, self.world, self.shard_rows = rank, world, shard_rows
+        self.render = render
+        self.s = Sampler(seed=seed, device=device, shard_index=rank, shard_count=world, shard_rows=shard_rows).create(render)
+        self.nw, self.nh = self.s.nw, self.s.nh
+        pr = self.s.padded_rows()
+        assert pr == padded_rows(self.nh, world, shard_rows)
+        self.dev = torch.device("cuda", device)
+        # the accumulator lives in a torch tensor so that RCCL can send it without a copy
+        self.local = torch.zeros((pr, self.nw, 3), dtype=torch.float32, device=self.dev)
+        self.s.bind_accum(self.local.data_ptr(), self.local.numel() * 4)
+        self.frame = torch.zeros((self.nh, self.nw, 3), dtype=torch.float32, device=self.dev) if rank == 0 else None
+        self.count = 0
+
+    def execute(self, n_samples: int = 1, gather: bool = True):
+        secs = self.s.execute(self.render, n_samples=n_samples)
+        self.count += n_samples
+        if gather:
+            gather_frame(self.local, self.nh, self.nw, self.shard_rows, dst=0, out=self.frame)
+        return secs
+
+    def img(self):
+        if self.rank != 0:
+            return None
+        import torch
+        torch.cuda.synchronize(self.dev)
+        self.s.set_accum_device(self.frame.data_ptr(), self.count)
+        return self.s.img()
+
+    def close(self):
+        self.s.close()

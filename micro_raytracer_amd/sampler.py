@@ -121,6 +121,26 @@ class Sampler:
         _lib.check(_lib.lib().mrt_accum_device_ptr(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def padded_rows(self) -> int:
+        self._need()
+        n = C.c_uint32()
+        _lib.check(_lib.lib().mrt_padded_rows(self._ctx, C.byref(n)))
+        return n.value
+
+    def bind_accum(self, dev_ptr, nbytes):
+        """Render into caller-owned device memory (a torch tensor's data_ptr()) from now on."""
+        self._need()
+        _lib.check(_lib.lib().mrt_bind_accum(self._ctx, C.c_void_p(dev_ptr), nbytes))
+
+    def set_accum_device(self, dev_ptr, count):
+        self._need()
+        _lib.check(_lib.lib().mrt_set_accum_device(self._ctx, C.c_void_p(dev_ptr), int(count)))
+
+    def create(self, render):
+        """Create the context without rendering (Sampler::new + scene upload)."""
+        self._ensure(render)
+        return self
+
     def set_accum(self, rgb, count):
         self._need()
         rgb = np.ascontiguousarray(rgb, np.float32)

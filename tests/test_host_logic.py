@@ -1,0 +1,200 @@
+"""Host-side logic without a GPU: the C-ABI library loads and exports its whole header, scene
+validation mirrors the reference's panics, the JSON loader applies the reference's defaults, the packed
+scene / octree / Lanczos taps agree with the oracle, and the kernel's per-lane code (compiled for x86,
+tests/emu) reproduces the oracle."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_holder
+
+
+def test_library_exports_every_declared_symbol():
+    from micro_raytracer_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "mrt.h")).read()
+    declared = set(re.findall(r"\b(mrt_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.mrt_abi_version() == 1
+
+
+def test_no_device_fails_loudly_not_silently():
+    """Without a GPU mrt_create must fail with MRT_ERR_DEVICE: there is no CPU fallback."""
+    from micro_raytracer_amd import MrtError, Sampler, _lib, load_render, scenes
+    if _lib.lib().mrt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(MrtError) as e:
+        Sampler().execute(load_render(scenes.default_scene(res=(16, 16))))
+    assert e.value.code == -3
+
+
+def _create_err(desc):
+    from micro_raytracer_amd import MrtError, Sampler, load_render
+    with pytest.raises(MrtError) as e:
+        Sampler().execute(load_render(desc))
+    return e.value
+
+
+def test_scene_validation_mirrors_reference_panics():
+    """Everything the reference would panic on mid-render is rejected up front with MRT_ERR_SCENE (-2)."""
+    from micro_raytracer_amd import scenes
+    base = scenes.default_scene(res=(16, 16))
+    d = json.loads(json.dumps(base)); d["scene"]["renderer"][0]["mat"] = {"emit": 1.5}
+    assert _create_err(d).code == -2                                   # gen_bool(1.5) panics, src/rt.rs:968
+    d = json.loads(json.dumps(base)); d["scene"]["renderer"][0]["mat"] = {"opacity": 1.2}
+    assert _create_err(d).code == -2                                   # gen_bool(<0) panics, src/rt.rs:1054
+    d = json.loads(json.dumps(base)); d["scene"]["renderer"] = [{"type": "triangle", "vtx": [[0, 0, 0], [1, 0, 0], [0, 0, 1]], "mat": {"tex": scenes.checker_texture(4, 4, 1)}}]
+    assert _create_err(d).code == -2                                   # todo!() in Triangle::uv, src/rt.rs:546
+    d = json.loads(json.dumps(base)); d["scene"]["renderer"][0]["mat"] = {"emap": {"w": 1, "h": 1, "dat": [[2.0, 0, 0]]}}
+    assert _create_err(d).code == -2
+    d = json.loads(json.dumps(base)); d["frame"]["ssaa"] = 0.01
+    assert _create_err(d).code == -2                                   # 16 * 0.01 truncates to a 0-pixel frame
+    d = json.loads(json.dumps(base)); d["scene"]["renderer"][0]["mat"] = {"opacity": -3.0, "emit": 1.0}
+    assert _create_err(d).code == -3                                   # legal in the reference -> reaches the device check
+
+
+def test_oracle_rejects_the_same_scenes(oracle_mod):
+    from micro_raytracer_amd import scenes
+    d = scenes.default_scene(res=(16, 16)); d["scene"]["renderer"][0]["mat"] = {"emit": -0.1}
+    _, h = make_holder(d)
+    with pytest.raises(ValueError):
+        oracle_mod.Oracle(h)
+
+
+def test_loader_defaults_match_reference_dump():
+    """README.md:405 (`raytrace -v -d --obj sphere --light point: -0.5 -1 0.5`) is the reference's own dump of every default."""
+    from micro_raytracer_amd import load_render
+    from micro_raytracer_amd.scene import dump_render
+    r = load_render({"scene": {"renderer": [{"type": "sphere", "r": 0.5}], "light": [{"type": "point", "pos": [-0.5, -1, 0.5]}]}})
+    d = dump_render(r)
+    f32 = lambda v: float(np.float32(v))
+    assert (d["rt"]["bounce"], d["rt"]["sample"], f32(d["rt"]["loss"])) == (8, 16, f32(0.15))
+    assert d["frame"]["res"] == [1280, 720] and d["frame"]["ssaa"] == 1.0
+    cam = d["frame"]["cam"]
+    assert cam["pos"] == [-0.0, -1.0, -0.0] and np.signbit(cam["pos"][0])
+    assert cam["dir"] == [0.0, 0.0, 1.0, 0.0]
+    assert [f32(cam[k]) for k in ("fov", "gamma", "exp", "aprt", "foc")] == [70.0, f32(0.8), f32(0.2), f32(0.001), 100.0]
+    m = d["scene"]["renderer"][0]["mat"]
+    assert m["albedo"] == [1.0, 1.0, 1.0] and (m["rough"], m["metal"], m["glass"], m["opacity"], m["emit"]) == (0, 0, 0, 1, 0)
+    assert all(m[k] is None for k in ("tex", "rmap", "mmap", "gmap", "omap", "emap"))
+    assert d["scene"]["light"][0] == {"type": "point", "pos": [-0.5, -1.0, 0.5], "pwr": 0.5, "color": [1.0, 1.0, 1.0]}
+    assert d["scene"]["sky"] == {"color": [0.0, 0.0, 0.0], "pwr": 0.5}
+    # default instance: pos 0, dir = Vec4f::backward() (src/parser.rs:847-851)
+    inst = d["scene"]["renderer"][0]["inst"]
+    assert inst == [[[0.0, 0.0, 0.0], [-0.0, -0.0, -1.0, -0.0]]]
+
+
+def test_loader_hex_colors_inline_assets_and_instances():
+    from micro_raytracer_amd import load_render, scenes
+    from micro_raytracer_amd.scene import Texture, mesh_to_inline, parse_color
+    assert np.array_equal(parse_color("#ffc177"), np.array([255, 193, 119], np.float32) / np.float32(255))
+    t = Texture(2, 1, np.array([[0.5, 0.25, 1.0], [0, 0, 0]], np.float32))
+    tris = scenes.icosphere(0, 0.3)
+    d = {"scene": {"renderer": [
+        {"type": "plane", "n": [0, 0, 1], "mat": {"tex": t.to_inline()}},
+        {"type": "mesh", "mesh": mesh_to_inline(tris), "pos": [1, 2, 3], "inst": [[[0, 0, 1], [0, 0, -1, 0]]]},
+    ]}}
+    r = load_render(d)
+    assert r.scene.renderer[0].mat.tex.w == 2 and np.array_equal(r.scene.renderer[0].mat.tex.dat, t.dat)
+    assert np.array_equal(r.scene.renderer[1].mesh, tris)
+    # pos given together with inst: (pos, backward) is inserted first (src/parser.rs:841-844)
+    inst = r.scene.renderer[1].inst
+    assert len(inst) == 2 and list(inst[0][0]) == [1, 2, 3] and list(inst[0][1]) == [-0.0, -0.0, -1.0, -0.0] and list(inst[1][0]) == [0, 0, 1]
+
+
+def test_packer_octree_equals_oracle_octree(oracle_mod, emu_mod):
+    from micro_raytracer_amd import scenes
+    for tris in (scenes.bumpy_mesh(967), scenes.icosphere(1, 0.22, (1.0, 1.0, 1.3)), scenes.icosphere(0, 1.0)):
+        d = {"frame": {"res": [8, 8]}, "scene": {"renderer": [{"type": "mesh", "mesh": [[[float(c) for c in v] for v in t] for t in tris]}]}}
+        _, h = make_holder(d)
+        ob, oc, oi = oracle_mod.Oracle(h).mesh_octree(0)
+        eb, ec, ei = emu_mod.octree(tris)
+        assert np.array_equal(ob.view(np.uint32), eb.view(np.uint32))
+        assert np.array_equal(oc, ec) and np.array_equal(oi, ei)
+        assert len(oc) <= 512 and oc.sum() == len(oi)
+
+
+def test_packer_texture_formats_and_sizes(emu_mod):
+    from micro_raytracer_amd import scenes
+    _, h = make_holder(scenes.minecraft_like(res=(16, 16), ssaa=1))
+    info = emu_mod.pack(h)
+    assert info["n_tex_u8"] == 11 and info["n_tex_f32"] == 0       # k/255 texels are stored as RGB8 + LUT
+    assert info["n_inst"] == 85 and info["n_rend"] == 9
+    assert info["blob_words"] * 4 < 160 * 1024                     # fits the LDS of one CU
+    d = scenes.default_scene(res=(16, 16)); d["scene"]["renderer"][0]["mat"] = {"tex": {"w": 1, "h": 1, "dat": [[0.3, 0.3, 0.3]]}}
+    _, h = make_holder(d)
+    assert emu_mod.pack(h)["n_tex_f32"] == 1                       # 0.3 is not k/255: kept as f32
+
+
+SCENES = {
+    "default": lambda S: S.default_scene(res=(64, 36), sample=3),
+    "cornell": lambda S: S.cornell_box(res=(48, 48), sample=4),
+    "cornell2": lambda S: S.cornell_box2(res=(32, 32), ssaa=2, sample=3),
+    "dof": lambda S: S.dof_scene(res=(64, 36), sample=3),
+    "instance": lambda S: S.instance_grid(res=(48, 27), sample=2, n=4),
+    "mesh": lambda S: S.mesh_scene(res=(48, 27), sample=2),
+    "minecraft": lambda S: S.minecraft_like(res=(48, 27), ssaa=1, sample=2),
+    "sink": lambda S: S.kitchen_sink(res=(64, 40), sample=6),
+    "ragged": lambda S: S.cornell_box(res=(21, 13), ssaa=1.5, sample=2),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_kernel_lane_code_matches_oracle_on_x86(name, oracle_mod, emu_mod):
+    """mrt_trace.h (the megakernel's per-lane body) compiled for x86 vs the oracle: <= 1e-4 on mean radiance,
+    and the image bytes produced by the kernels' per-element bodies are identical."""
+    from micro_raytracer_amd import scenes
+    render, h = make_holder(SCENES[name](scenes))
+    spp = render.rt.sample
+    o = oracle_mod.Oracle(h, seed=5)
+    o.execute(spp)
+    ref, _ = o.accum()
+    got, seg = emu_mod.render(h, 5, spp)
+    assert (np.isnan(got) == np.isnan(ref)).all()
+    assert np.nanmax(np.abs(got - ref)) / spp <= 1e-5
+    assert 0 < seg <= o.segments          # the kernel stops a path at an emitting hit, the reference traces on
+    o.set_accum(got, spp)
+    ss, out = emu_mod.img(h, got, spp)
+    assert np.array_equal(ss, o.img_ss()) and np.array_equal(out, o.img())
+
+
+def test_oracle_is_independent_of_tiling_and_threads(oracle_mod):
+    from micro_raytracer_amd import scenes
+    _, h = make_holder(scenes.cornell_box(res=(40, 24), sample=2))
+    a = oracle_mod.Oracle(h, seed=2); a.execute(2, threads=1, n_dim=64)
+    b = oracle_mod.Oracle(h, seed=2); b.execute(1, threads=5, n_dim=3); b.execute(1, threads=2, n_dim=7)
+    assert np.array_equal(a.accum()[0], b.accum()[0])
+    c = oracle_mod.Oracle(h, seed=3); c.execute(2)
+    assert not np.array_equal(a.accum()[0], c.accum()[0])
+
+
+def test_lanczos_matches_reference_shape_properties(oracle_mod):
+    """image 0.24 Lanczos3: identity when sizes match, constant images stay constant, taps normalised."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(12, 20, 3), dtype=np.uint8)
+    assert np.array_equal(oracle_mod.lanczos3_resize(img, 20, 12), img)
+    const = np.full((40, 60, 3), 137, np.uint8)
+    assert (oracle_mod.lanczos3_resize(const, 30, 20) == 137).all()
+    L = oracle_mod.lib()
+    w = (C.c_float * 64)(); left = C.c_uint32()
+    for o_idx in (0, 7, 29):
+        n = L.orc_lanczos3_weights(60, 30, o_idx, C.byref(left), w, 64)
+        assert 6 <= n <= 14 and abs(sum(w[i] for i in range(n)) - 1.0) < 1e-5
+
+
+def test_tonemap_known_answers(oracle_mod):
+    """(255 * t(c^gamma)) as u8 with t(v) = v (1 + v / (1-exp)^2) / (1 + v), src/sampler.rs:88-94."""
+    for c, gamma, exp in ((0.25, 0.8, 0.2), (1.7, 0.5, 0.75), (0.0, 0.8, 0.2), (1e9, 0.6, 0.8)):
+        got = oracle_mod.tonemap_px([c * 4, c * 4, c * 4], 4, gamma, exp)[0]
+        g = float(c) ** gamma
+        want = 255.0 * (g * (1 + g / (1 - exp) ** 2) / (1 + g))
+        want = 0 if not want > 0 else min(255, int(want))
+        assert abs(int(got) - want) <= 1
+    # `as u8` saturates and maps NaN to 0; powf of a negative base is NaN
+    assert oracle_mod.tonemap_px([np.nan, -1.0, 0.0], 1, 0.8, 0.2).tolist() == [0, 0, 0]
