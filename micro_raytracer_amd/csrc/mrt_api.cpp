@@ -199,7 +199,7 @@ int mrt_execute(mrt_ctx *c, uint32_t n_samples, double *seconds)
         c->P.n_samples = n_samples;
         c->P.sample_base = c->count;
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
-        HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->stream));
+        HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         float ms = 0;

@@ -20,8 +20,12 @@ namespace mrt {
 // Workgroup = tiles_x x tiles_y wavefronts, each wavefront an 8x8 pixel tile (64 lanes): neighbouring
 // pixels share most of their path prefix, which keeps the per-lane predicates of the uniform traversal
 // loop coherent.  Rows are the shard-local rows of this context (block-cyclic over shards).
-template <bool SCENE_IN_LDS, int BLOCK_THREADS>
-__global__ void __launch_bounds__(BLOCK_THREADS) pt_megakernel(const Params P)
+#ifndef MRT_WAVES_PER_EU
+#define MRT_WAVES_PER_EU 2
+#endif
+
+template <bool SCENE_IN_LDS, int BLOCK_THREADS, u32 FEAT>
+__global__ void __launch_bounds__(BLOCK_THREADS, MRT_WAVES_PER_EU) pt_megakernel(const Params P)
 {
     extern __shared__ uint4 lds_blob[];
     const float *F;
@@ -51,7 +55,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) pt_megakernel(const Params P)
         S.P = &P;
         float *px = P.accum + ((size_t)ry * P.nw + x) * 3u;
         V3 acc = v3(px[0], px[1], px[2]);
-        render_pixel(S, x, y, acc, segments);
+        render_pixel<FEAT>(S, x, y, acc, segments);
         px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
     }
     if (P.count_segments) {
@@ -131,27 +135,51 @@ __global__ void math_selftest(int op, const float *a, const float *b, float *out
 }
 
 // ---- launchers (declared in mrt_kernels.h) ----
-hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, hipStream_t stream)
+// One instantiation per feature set for the common launch shape (scene in LDS, 256 threads); the 512-thread
+// shape (one LDS copy per CU, scenes of 78-160 KB) and the scene-in-L2 fallback carry every feature.
+template <u32 FEAT>
+static void launch_lds256(dim3 grid, size_t lds, hipStream_t stream, const Params &P)
+{
+    hipLaunchKernelGGL((pt_megakernel<true, 256, FEAT>), grid, dim3(256), lds, stream, P);
+}
+
+using LaunchFn = void (*)(dim3, size_t, hipStream_t, const Params &);
+static const LaunchFn kLds256[16] = {
+    launch_lds256<0>, launch_lds256<1>, launch_lds256<2>, launch_lds256<3>, launch_lds256<4>, launch_lds256<5>,
+    launch_lds256<6>, launch_lds256<7>, launch_lds256<8>, launch_lds256<9>, launch_lds256<10>, launch_lds256<11>,
+    launch_lds256<12>, launch_lds256<13>, launch_lds256<14>, launch_lds256<15>};
+
+hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 features, hipStream_t stream)
 {
     if (block_threads != P.tiles_x * P.tiles_y * 64u || (block_threads != 256u && block_threads != 512u)) return hipErrorInvalidConfiguration;
     const u32 tile_w = P.tiles_x * 8u, tile_h = P.tiles_y * 8u;
     dim3 grid((P.nw + tile_w - 1) / tile_w, (P.local_rows + tile_h - 1) / tile_h);
     const size_t lds = scene_in_lds ? (size_t)P.blob_words * 4u : 0;
     if (scene_in_lds) {
-        if (block_threads == 256u) hipLaunchKernelGGL((pt_megakernel<true, 256>), grid, dim3(256), lds, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<true, 512>), grid, dim3(512), lds, stream, P);
+        if (block_threads == 256u) kLds256[features & F_ALL](grid, lds, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<true, 512, F_ALL>), grid, dim3(512), lds, stream, P);
     } else {
-        if (block_threads == 256u) hipLaunchKernelGGL((pt_megakernel<false, 256>), grid, dim3(256), 0, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<false, 512>), grid, dim3(512), 0, stream, P);
+        if (block_threads != 256u) return hipErrorInvalidConfiguration;
+        hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL>), grid, dim3(256), 0, stream, P);
     }
     return hipGetLastError();
 }
 
+template <u32 FEAT>
+static hipError_t set_lds_attr(int bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 256, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 hipError_t configure_pt(size_t max_lds_bytes)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+    const int b = (int)max_lds_bytes;
+    hipError_t e;
+#define MRT_SET(F) if ((e = set_lds_attr<F>(b)) != hipSuccess) return e;
+    MRT_SET(0) MRT_SET(1) MRT_SET(2) MRT_SET(3) MRT_SET(4) MRT_SET(5) MRT_SET(6) MRT_SET(7)
+    MRT_SET(8) MRT_SET(9) MRT_SET(10) MRT_SET(11) MRT_SET(12) MRT_SET(13) MRT_SET(14) MRT_SET(15)
+#undef MRT_SET
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 512, F_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
 }
 
 hipError_t launch_tonemap(const float *accum, unsigned char *out, u32 n_px, float rc, float gamma, float wexp, hipStream_t stream)

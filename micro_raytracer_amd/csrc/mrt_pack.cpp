@@ -296,6 +296,9 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
         const int32_t maps[6] = {o.mat.tex, o.mat.rmap, o.mat.mmap, o.mat.gmap, o.mat.omap, o.mat.emap};
         bool any_map = false;
         for (int k = 0; k < 6; ++k) any_map |= maps[k] >= 0;
+        if (any_map) out.features |= 4u;                                             // F_MAPS
+        if (o.kind == MRT_KIND_BOX || o.kind == MRT_KIND_MESH) out.features |= 1u;   // F_BOX
+        if (o.kind == MRT_KIND_TRIANGLE || o.kind == MRT_KIND_MESH) out.features |= 2u;   // F_TRI
         rec[REND_FLAGS] = any_map ? RF_HAS_MAPS : 0u;
         H3 nn = h3(0, 0, 0), nraw = h3(0, 0, 0);
         if (o.kind == MRT_KIND_SPHERE) {
@@ -375,6 +378,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     if (xf_tab.empty()) { const float dflt[4] = {-0.0f, -0.0f, -1.0f, -0.0f}; xf_of(dflt); }
 
     P.n_rend = sc.n_renderer; P.n_inst = n_inst_total; P.n_light = sc.n_light;
+    if (sc.n_light) out.features |= 8u;                                              // F_LIGHTS
     P.off_rend = B.align4(); B.w.insert(B.w.end(), rend_tab.begin(), rend_tab.end());
     P.off_inst = B.align4(); B.w.insert(B.w.end(), inst_tab.begin(), inst_tab.end());
     P.off_xf = B.align4(); for (float v : xf_tab) B.f(v);

@@ -16,6 +16,16 @@
 
 namespace mrt {
 
+// Scene features a kernel instantiation is compiled for; the host picks the smallest set that covers the
+// scene, so e.g. a Cornell box of planes and spheres carries no octree walker, texture fetch or shadow-ray code.
+enum : u32 {
+    F_BOX = 1u,       // boxes or meshes present: rays need the patched reciprocal direction (src/rt.rs:303-316)
+    F_TRI = 2u,       // triangle / mesh renderers present
+    F_MAPS = 4u,      // some material has a texture map
+    F_LIGHTS = 8u,    // the scene has lights (shadow rays + direct term)
+    F_ALL = 15u
+};
+
 constexpr float kE = 0.0001f;                 // src/rt.rs:7
 constexpr float kBig = 1.0f / 0.0001f;        // E.recip(), src/rt.rs:307
 
@@ -210,11 +220,13 @@ struct RayPre {
     bool d_ok;     // nzfin3(d)
 };
 
+template <u32 FEAT>
 MRT_HD RayPre ray_pre(V3 o, V3 d)
 {
     RayPre r;
     r.o = o; r.d = d;
-    r.m = recip_patched(d);
+    if constexpr (FEAT & F_BOX) r.m = recip_patched(d);
+    else r.m = v3(0.0f, 0.0f, 0.0f);
     r.dd = dot(d, d);
     r.d_ok = nzfin3(d);
     return r;
@@ -277,13 +289,13 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, float
 // RayTracer::closest_hit, src/rt.rs:867-898: every renderer x instance in order, first minimum of
 // the entry distance under f32::total_cmp.  ANY = true answers only Some / None (the shadow query
 // of src/rt.rs:1036).
-template <bool ANY>
+template <bool ANY, u32 FEAT>
 MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
 {
     const float *F = S.F;
     const Params &P = *S.P;
     i32 best_key = 0x7fffffff;
-    best.rend = -1;
+    best.rend = -1; best.inst = 0; best.t0 = 0.0f; best.t1 = 0.0f; best.i0 = -1; best.i1 = -1;
     for (u32 r = 0; r < P.n_rend; ++r) {
         const float *R = F + P.off_rend + r * REND_WORDS;
         const u32 kind = ldu(R, REND_KIND), ioff = ldu(R, REND_INST_OFF), icnt = ldu(R, REND_INST_CNT);
@@ -299,7 +311,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
             float dd = ray.dd;
             if (!fast_d) {
                 rd = xf_full(X, ray.d);
-                m = recip_patched(rd);
+                if constexpr (FEAT & F_BOX) m = recip_patched(rd);
                 dd = dot(rd, rd);
             }
             float t0 = 0.0f, t1 = 0.0f;
@@ -310,13 +322,15 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
             } else if (kind == KIND_PLANE) {
                 hit = plane_isect(ld3(R, REND_GEO), I[INST_PLANE_D], ro, rd, t0);
                 t1 = t0;
-            } else if (kind == KIND_BOX) {
+            } else if ((FEAT & F_BOX) && kind == KIND_BOX) {
                 hit = box_isect(ld3(R, REND_GEO), ro, m, pos, t0, t1);
-            } else if (kind == KIND_TRIANGLE) {
+            } else if ((FEAT & F_TRI) && kind == KIND_TRIANGLE) {
                 hit = tri_isect(add(ld3(R, REND_GEO), pos), ld3(R, REND_GEO + 3), ld3(R, REND_GEO + 6), ro, rd, t0);
                 t1 = t0;
-            } else {
+            } else if ((FEAT & F_TRI) && (FEAT & F_BOX) && kind == KIND_MESH) {
                 hit = mesh_isect<ANY>(S, ldu(R, REND_GEO), ro, rd, m, pos, t0, i0, t1, i1);
+            } else {
+                hit = false;
             }
             if (hit) {
                 if (ANY) return true;
@@ -352,14 +366,15 @@ MRT_HD Obj obj_of(const Scn &S, const Hit &h)
 MRT_HD V3 to_object(const Obj &o, V3 hp) { return add(o.pos, xf_vec(o.X, o.ident, sub(hp, o.pos))); }
 
 // Renderer::normal, src/rt.rs:776-793 with the Normal impls, src/rt.rs:414-466
+template <u32 FEAT>
 MRT_HD V3 hit_normal(const Scn &S, const Obj &o, V3 n_hit, i32 tri_idx)
 {
     if (o.kind == KIND_PLANE) return ld3(o.I, INST_PLANE_NW);          // norm(R*(L*n)) is per instance
-    V3 n;
+    V3 n = v3(0.0f, 0.0f, 0.0f);
     if (o.kind == KIND_SPHERE) n = sub(n_hit, o.pos);
-    else if (o.kind == KIND_BOX) n = box_normal(ld3(o.R, REND_GEO + 3), n_hit, o.pos);
-    else if (o.kind == KIND_TRIANGLE) n = cross(ld3(o.R, REND_GEO + 3), ld3(o.R, REND_GEO + 6));
-    else {
+    else if ((FEAT & F_BOX) && o.kind == KIND_BOX) n = box_normal(ld3(o.R, REND_GEO + 3), n_hit, o.pos);
+    else if ((FEAT & F_TRI) && o.kind == KIND_TRIANGLE) n = cross(ld3(o.R, REND_GEO + 3), ld3(o.R, REND_GEO + 6));
+    else if (FEAT & F_TRI) {
         const float *M = S.F + S.P->off_mesh + ldu(o.R, REND_GEO) * MESH_WORDS;
         const float *T = S.F + S.P->off_tri + (ldu(M, MESH_TRI0) + (u32)tri_idx) * TRI_WORDS;
         n = cross(ld3(T, 3), ld3(T, 6));
@@ -395,13 +410,17 @@ struct Surf {
     bool maps;
     UV uv;
 };
+template <u32 FEAT>
 MRT_HD Surf surf_of(const Scn &S, const Hit &h, const Obj &o, V3 n_hit)
 {
     Surf s;
     s.M = S.F + S.P->off_mat + (u32)h.rend * MAT_WORDS;
-    s.maps = (ldu(o.R, REND_FLAGS) & RF_HAS_MAPS) != 0;
+    s.maps = false;
     s.uv.x = 0.0f; s.uv.y = 0.0f;
-    if (s.maps) s.uv = hit_uv(o, n_hit);
+    if constexpr (FEAT & F_MAPS) {
+        s.maps = (ldu(o.R, REND_FLAGS) & RF_HAS_MAPS) != 0;
+        if (s.maps) s.uv = hit_uv(o, n_hit);
+    }
     return s;
 }
 MRT_HD float surf_scalar(const Scn &S, const Surf &s, u32 slot, u32 field)
@@ -471,6 +490,7 @@ MRT_HD u32 dim_of(u32 bounce, u32 slot) { return DIM_BOUNCE0 + bounce * DIMS_PER
 // All samples of one supersampled pixel: Sampler::execute's per-pixel body, n_samples times
 // (src/sampler.rs:45-70 calling RayTracer::iter / reduce_light, src/rt.rs:937-994, whose iterator
 // is RaytraceIterator::next, src/rt.rs:1014-1066).  acc is the running colors[(x, y)] entry.
+template <u32 FEAT>
 MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
 {
     const Params &P = *S.P;
@@ -496,10 +516,10 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
             fresh = false;
         }
         // ---- RaytraceIterator::next ----
-        const RayPre ray = ray_pre(o, d);
+        const RayPre ray = ray_pre<FEAT>(o, d);
         Hit h;
         ++seg;
-        if (!trace<false>(S, ray, h)) {
+        if (!trace<false, FEAT>(S, ray, h)) {
             // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
             const V3 c = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
             acc = add(acc, c);
@@ -509,7 +529,7 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
         const Obj ob = obj_of(S, h);
         const V3 p0 = add(o, muls(d, h.t0));                       // Vec3f::from(&hit.0.ray)
         const V3 nh0 = to_object(ob, p0);
-        const Surf sf0 = surf_of(S, h, ob, nh0);
+        const Surf sf0 = surf_of<FEAT>(S, h, ob, nh0);
         const float opacity0 = surf_scalar(S, sf0, MAP_OPACITY, MAT_OPACITY);
         const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
 
@@ -521,8 +541,8 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
         if (bernoulli(fmin_(1.0f - opacity0, 0.85f), draw_u32(pk, dim_of(b, SL_OPAC_COIN)))) {
             const V3 p1 = add(o, muls(d, h.t1));
             const V3 nh1 = to_object(ob, p1);
-            const V3 n1 = hit_normal(S, ob, nh1, h.i1);
-            const Surf sf1 = surf_of(S, h, ob, nh1);
+            const V3 n1 = hit_normal<FEAT>(S, ob, nh1, h.i1);
+            const Surf sf1 = surf_of<FEAT>(S, h, ob, nh1);
             float rough = surf_scalar(S, sf1, MAP_ROUGH, MAT_ROUGH);      // Ray::refract, src/rt.rs:574-589
             const float opac1 = surf_scalar(S, sf1, MAP_OPACITY, MAT_OPACITY);
             if (metal_c == 0.0f && opac1 != 0.0f && bernoulli(0.80f, draw_u32(pk, dim_of(b, SL_REFR_COIN)))) rough = 1.0f;
@@ -535,7 +555,7 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
                 hp = p1; hn = n1; sfh = sf1;
             }
         }
-        if (!refracted) hn = hit_normal(S, ob, nh0, h.i0);
+        if (!refracted) hn = hit_normal<FEAT>(S, ob, nh0, h.i0);
         const V3 n0 = hn;   // when not refracted this is hit0's normal (used by reflect below)
 
         // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
@@ -549,7 +569,7 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
 
         // direct light, visibility from hit0 (src/rt.rs:1027-1046), shading at the recorded hit (:973-987)
         V3 l_col = v3(0.0f, 0.0f, 0.0f);
-        if (P.n_light) {
+        if ((FEAT & F_LIGHTS) && P.n_light) {
             const float rough_h = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);
             const float metal_h = surf_scalar(S, sfh, MAP_METAL, MAT_METAL);
             for (u32 li = 0; li < P.n_light; ++li) {
@@ -559,7 +579,7 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
                 const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
                 const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
                 Hit hs;
-                if (trace<true>(S, ray_pre(so, ls), hs)) continue;
+                if (trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs)) continue;
                 const V3 ln = point ? norm(sub(lv, hp)) : lv;             // l.norm() at the recorded hit
                 const float diff = fmax_(dot(ln, hn), 0.0f);
                 const float sp = fmax_(dot(d, reflect(ln, hn)), 0.0f);
