@@ -6,7 +6,7 @@ import subprocess
 from . import _abi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmrt_hip.so")
+LIB_PATH = os.environ.get("MRT_LIB") or os.path.join(_PKG, "libmrt_hip.so")   # MRT_LIB: experiment builds only
 _LIB = None
 
 # every symbol include/mrt.h declares

@@ -20,12 +20,21 @@ namespace mrt {
 // Workgroup = tiles_x x tiles_y wavefronts, each wavefront an 8x8 pixel tile (64 lanes): neighbouring
 // pixels share most of their path prefix, which keeps the per-lane predicates of the uniform traversal
 // loop coherent.  Rows are the shard-local rows of this context (block-cyclic over shards).
-#ifndef MRT_WAVES_PER_EU
-#define MRT_WAVES_PER_EU 2
+// Register budget per instantiation (second __launch_bounds__ argument = minimum waves per SIMD).  The kernel is
+// VALU-issue bound, so the light variants (planes / spheres / boxes, no maps, no lights, no triangles) are squeezed to
+// 6 waves per SIMD (80 VGPRs, a few spills: measured +14 % on the Cornell box); the heavier variants lose more to
+// spills than they gain from occupancy and keep the compiler's choice.  MRT_WAVES_PER_EU overrides (experiments).
+constexpr int waves_for(u32 feat)
+{
+#ifdef MRT_WAVES_PER_EU
+    return MRT_WAVES_PER_EU;
+#else
+    return (feat & ~F_BOX) == 0 ? 6 : 2;
 #endif
+}
 
 template <bool SCENE_IN_LDS, int BLOCK_THREADS, u32 FEAT>
-__global__ void __launch_bounds__(BLOCK_THREADS, MRT_WAVES_PER_EU) pt_megakernel(const Params P)
+__global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(const Params P, const u32 *__restrict__ blob_g)
 {
     extern __shared__ uint4 lds_blob[];
     const float *F;
@@ -52,6 +61,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, MRT_WAVES_PER_EU) pt_megakernel
     if (active) {
         Scn S;
         S.F = F;
+#ifdef MRT_UNIFORM_SMEM
+        S.U = reinterpret_cast<const float *>(blob_g);
+#else
+        S.U = F;
+#endif
         S.P = &P;
         float *px = P.accum + ((size_t)ry * P.nw + x) * 3u;
         V3 acc = v3(px[0], px[1], px[2]);
@@ -140,7 +154,7 @@ __global__ void math_selftest(int op, const float *a, const float *b, float *out
 template <u32 FEAT>
 static void launch_lds256(dim3 grid, size_t lds, hipStream_t stream, const Params &P)
 {
-    hipLaunchKernelGGL((pt_megakernel<true, 256, FEAT>), grid, dim3(256), lds, stream, P);
+    hipLaunchKernelGGL((pt_megakernel<true, 256, FEAT>), grid, dim3(256), lds, stream, P, P.blob);
 }
 
 using LaunchFn = void (*)(dim3, size_t, hipStream_t, const Params &);
@@ -157,10 +171,10 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     const size_t lds = scene_in_lds ? (size_t)P.blob_words * 4u : 0;
     if (scene_in_lds) {
         if (block_threads == 256u) kLds256[features & F_ALL](grid, lds, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<true, 512, F_ALL>), grid, dim3(512), lds, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<true, 512, F_ALL>), grid, dim3(512), lds, stream, P, P.blob);
     } else {
         if (block_threads != 256u) return hipErrorInvalidConfiguration;
-        hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL>), grid, dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL>), grid, dim3(256), 0, stream, P, P.blob);
     }
     return hipGetLastError();
 }

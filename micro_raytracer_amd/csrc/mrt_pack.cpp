@@ -223,6 +223,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     P.aprt = fr.cam.aprt; P.foc = fr.cam.foc;
     lookat(h3(fr.cam.dir[1], fr.cam.dir[2], fr.cam.dir[3]), P.cam_L);
     rotate_y(fr.cam.dir[0], P.cam_R);
+    P.cam_ident = (is_identity(P.cam_L) && is_identity(P.cam_R)) ? 1u : 0u;
     P.bounce = d->rt.bounce;
     if (P.bounce > 0x0fffffffu) { err = "bounce too large"; return MRT_ERR_LIMIT; }
     P.q = 1.0f - min_num(d->rt.loss, 1.0f);
@@ -284,7 +285,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
         return id;
     };
 
-    std::vector<u32> rend_tab, inst_tab, mat_tab, mesh_tab, leaf_tab;
+    std::vector<u32> rend_tab, inst_tab, instx_tab, mat_tab, mesh_tab, leaf_tab;
     std::vector<float> tri_tab, node_tab;
     u32 n_inst_total = 0;
     for (u32 r = 0; r < sc.n_renderer; ++r) {
@@ -354,17 +355,26 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
         for (u32 i = 0; i < o.n_inst; ++i) {
             const mrt_instance &in = o.inst[i];
             u32 ir[INST_WORDS] = {0};
+            u32 ix[INSTX_WORDS] = {0};
             const H3 pos = h3(in.pos[0], in.pos[1], in.pos[2]);
             ir[INST_POS] = bits(pos.x); ir[INST_POS + 1] = bits(pos.y); ir[INST_POS + 2] = bits(pos.z);
             const u32 xf = xf_of(in.dir);
-            ir[INST_XF] = xf;
-            if (o.kind == MRT_KIND_PLANE) {
-                ir[INST_PLANE_D] = bits(hdot(hneg(nn), pos));                                   // src/rt.rs:404
+            if (xf >= (1u << 28)) { err = "too many distinct instance directions"; return MRT_ERR_LIMIT; }
+            ir[INST_TAG] = o.kind | (bits(xf_tab[(size_t)xf * XF_WORDS + XF_IDENT]) ? TAG_IDENT : 0u) | (xf << TAG_XF_SHIFT);
+            ix[INSTX_REND] = r;
+            if (o.kind == MRT_KIND_SPHERE) {
+                ir[INST_P3] = rec[REND_GEO];                                                    // r * r
+            } else if (o.kind == MRT_KIND_PLANE) {
+                ir[INST_P3] = bits(hdot(hneg(nn), pos));                                        // src/rt.rs:404
+                ir[INST_P5] = bits(nn.x); ir[INST_P5 + 1] = bits(nn.y); ir[INST_P5 + 2] = bits(nn.z);
                 const float *X = xf_tab.data() + (size_t)xf * XF_WORDS;
                 const H3 nw = hnorm(mul3(X + XF_R, mul3(X + XF_L, nraw)));                      // src/rt.rs:786,792
-                ir[INST_PLANE_NW] = bits(nw.x); ir[INST_PLANE_NW + 1] = bits(nw.y); ir[INST_PLANE_NW + 2] = bits(nw.z);
+                ix[INSTX_PLANE_NW] = bits(nw.x); ix[INSTX_PLANE_NW + 1] = bits(nw.y); ix[INSTX_PLANE_NW + 2] = bits(nw.z);
+            } else if (o.kind == MRT_KIND_BOX) {
+                ir[INST_P3] = rec[REND_GEO]; ir[INST_P5] = rec[REND_GEO + 1]; ir[INST_P5 + 1] = rec[REND_GEO + 2];   // 0.5 * sizes
             }
             inst_tab.insert(inst_tab.end(), ir, ir + INST_WORDS);
+            instx_tab.insert(instx_tab.end(), ix, ix + INSTX_WORDS);
         }
         n_inst_total += o.n_inst;
 
@@ -381,6 +391,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     if (sc.n_light) out.features |= 8u;                                              // F_LIGHTS
     P.off_rend = B.align4(); B.w.insert(B.w.end(), rend_tab.begin(), rend_tab.end());
     P.off_inst = B.align4(); B.w.insert(B.w.end(), inst_tab.begin(), inst_tab.end());
+    P.off_instx = B.align4(); B.w.insert(B.w.end(), instx_tab.begin(), instx_tab.end());
     P.off_xf = B.align4(); for (float v : xf_tab) B.f(v);
     P.off_mat = B.align4(); B.w.insert(B.w.end(), mat_tab.begin(), mat_tab.end());
     P.off_light = B.align4();

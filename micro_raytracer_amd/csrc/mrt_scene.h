@@ -34,8 +34,17 @@ enum : u32 { RF_HAS_MAPS = 1u };
 // geometry words: sphere [4] r*r | plane [4..6] n^, [7..9] n | box [4..6] half, [7..9] (1/size)*2 |
 // triangle [4..6] v0, [7..9] e0, [10..12] e1 | mesh [4] mesh index
 
-// INST: [0..2] pos  [3] plane d  [4] xf index  [5..7] plane world normal norm(R*(L*n))
-enum : u32 { INST_POS = 0, INST_PLANE_D = 3, INST_XF = 4, INST_PLANE_NW = 5 };
+// INST (the flat traversal table, one record per renderer instance in the reference's iteration order;
+// two aligned 16-byte reads, everything the common kinds need):
+//   [0..2] pos
+//   [3]    sphere r*r | plane d = (-n^).pos | box half.x
+//   [4]    tag = kind | identity-valued transform ? 8 : 0 | xf index << 4
+//   [5..7] plane n^ | box [5] half.y [6] half.z
+// INSTX (read per lane after a hit): [0] renderer index  [1..3] plane world normal norm(R*(L*n))
+enum : u32 { INST_POS = 0, INST_P3 = 3, INST_TAG = 4, INST_P5 = 5 };
+enum : u32 { INSTX_REND = 0, INSTX_PLANE_NW = 1 };
+constexpr u32 INSTX_WORDS = 4;
+constexpr u32 TAG_KIND_MASK = 7u, TAG_IDENT = 8u, TAG_XF_SHIFT = 4u;
 
 // XF: [0..8] L (lookat)  [9..17] R (rotate_y)  [18] 1 if both equal the identity as values
 enum : u32 { XF_L = 0, XF_R = 9, XF_IDENT = 18 };
@@ -74,11 +83,12 @@ struct Params {
     float cam_pos[3];
     float aprt, foc;
     float cam_L[9], cam_R[9];   // lookat(cam.dir, up), rotate_y(cam.dir), src/rt.rs:925-927
+    u32 cam_ident;              // both equal the identity as values
     float sky[3];
     float sky_init[3];       // sky.color * sky.pwr, src/rt.rs:964
     // scene tables
     u32 n_rend, n_light, n_inst;
-    u32 off_rend, off_inst, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
+    u32 off_rend, off_inst, off_instx, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
     u32 blob_words;
     u32 tiles_x, tiles_y;    // 8x8-pixel wave tiles per workgroup in x and y
     u32 count_segments;

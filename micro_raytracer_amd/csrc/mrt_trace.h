@@ -46,6 +46,8 @@ MRT_HD V3 m3mul(const float *m, V3 v)                                           
     return v3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
 }
 MRT_HD V3 ld3(const float *F, u32 i) { return v3(F[i], F[i + 1], F[i + 2]); }
+struct alignas(16) F4 { float x, y, z, w; };
+MRT_HD F4 ld4(const float *F, u32 i) { return *reinterpret_cast<const F4 *>(F + i); }   // i % 4 == 0 (records are 16-byte aligned)
 MRT_HD u32 ldu(const float *F, u32 i) { return f2u(F[i]); }
 
 // true when x is neither zero, infinite nor NaN
@@ -98,6 +100,14 @@ MRT_HD bool sphere_isect(float r2, V3 oo, V3 rd, float a, float &t0, float &t1)
     const float c = dot(oo, oo) - r2;
     const float disc = b * b - 4.0f * a * c;
     if (disc < 0.0f) return false;
+    // Moving away from the centre (b > 0): t0 = (-b - sqrt(disc)) / (2a) is negative, i.e. the `t0 < 0` miss of
+    // src/rt.rs:353, without evaluating the sqrt and the divisions.  The guards keep this exact: disc >= 0 excludes
+    // NaN, and with b > 1e-20 and 0 < a < 1e18 the quotient is a non-zero negative number (no underflow to -0,
+    // which the reference would accept as a hit at t0 = -0).
+    if (b > 1e-20f && a > 0.0f && a < 1e18f && disc >= 0.0f) return false;
+#ifdef MRT_ABL_NOSPHEREMATH
+    t0 = -b * 0.5f; t1 = t0; return t0 > 0.0f;
+#endif
     const float sq = sqrt_(disc);
     const float q0 = (-b - sq) / (2.0f * a);
     if (q0 < 0.0f) return false;
@@ -128,7 +138,11 @@ MRT_HD bool tri_isect(V3 vp, V3 e0, V3 e1, V3 ro, V3 rd, float &t)
 // Plane::intersect, src/rt.rs:400-412; nn = norm(n), d = (-nn).pos
 MRT_HD bool plane_isect(V3 nn, float d, V3 ro, V3 rd, float &t)
 {
+#ifdef MRT_ABL_NODIV
+    const float tt = -(dot(ro, nn) + d) * __builtin_amdgcn_rcpf(dot(rd, nn));
+#else
     const float tt = -(dot(ro, nn) + d) / dot(rd, nn);
+#endif
     if (tt <= 0.0f) return false;
     t = tt;
     return true;
@@ -180,7 +194,9 @@ MRT_HD uint64_t to_index(float v)
 }
 
 struct Scn {
-    const float *F;      // the packed scene (LDS)
+    const float *F;      // the packed scene (LDS): per-lane (divergent) lookups
+    const float *U;      // the same blob for wave-uniform reads of the traversal loop: LDS, or global memory
+                         // read through the scalar cache into SGPRs (MRT_UNIFORM_SMEM)
     const Params *P;
 };
 
@@ -288,66 +304,77 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, float
 
 // RayTracer::closest_hit, src/rt.rs:867-898: every renderer x instance in order, first minimum of
 // the entry distance under f32::total_cmp.  ANY = true answers only Some / None (the shadow query
-// of src/rt.rs:1036).
+// of src/rt.rs:1036).  The loop runs over the flat instance table; each record is fetched one
+// iteration ahead so that its LDS latency is covered by the previous primitive's arithmetic.
 template <bool ANY, u32 FEAT>
 MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
 {
-    const float *F = S.F;
+    const float *F = S.U;
     const Params &P = *S.P;
     i32 best_key = 0x7fffffff;
     best.rend = -1; best.inst = 0; best.t0 = 0.0f; best.t1 = 0.0f; best.i0 = -1; best.i1 = -1;
-    for (u32 r = 0; r < P.n_rend; ++r) {
-        const float *R = F + P.off_rend + r * REND_WORDS;
-        const u32 kind = ldu(R, REND_KIND), ioff = ldu(R, REND_INST_OFF), icnt = ldu(R, REND_INST_CNT);
-        for (u32 i = ioff; i < ioff + icnt; ++i) {
-            const float *I = F + P.off_inst + i * INST_WORDS;
-            const V3 pos = ld3(I, INST_POS);
-            const float *X = F + P.off_xf + ldu(I, INST_XF) * XF_WORDS;
-            const bool ident = ldu(X, XF_IDENT) != 0;
-            // Renderer::intersect, src/rt.rs:725-733: n_ray.orig = pos + R*(L*(orig - pos)), n_ray.dir = R*(L*dir)
-            const V3 ro = add(pos, xf_vec(X, ident, sub(ray.o, pos)));
-            const bool fast_d = ident && ray.d_ok;
-            V3 rd = ray.d, m = ray.m;
-            float dd = ray.dd;
-            if (!fast_d) {
-                rd = xf_full(X, ray.d);
-                if constexpr (FEAT & F_BOX) m = recip_patched(rd);
-                dd = dot(rd, rd);
-            }
-            float t0 = 0.0f, t1 = 0.0f;
-            i32 i0 = -1, i1 = -1;
-            bool hit;
-            if (kind == KIND_SPHERE) {
-                hit = sphere_isect(R[REND_GEO], sub(ro, pos), rd, dd, t0, t1);
-            } else if (kind == KIND_PLANE) {
-                hit = plane_isect(ld3(R, REND_GEO), I[INST_PLANE_D], ro, rd, t0);
-                t1 = t0;
-            } else if ((FEAT & F_BOX) && kind == KIND_BOX) {
-                hit = box_isect(ld3(R, REND_GEO), ro, m, pos, t0, t1);
-            } else if ((FEAT & F_TRI) && kind == KIND_TRIANGLE) {
+    const u32 n = P.n_inst;
+    if (n == 0) return false;
+    const float *I = F + P.off_inst;
+    F4 qa = ld4(I, 0), qb = ld4(I, 4);
+    for (u32 i = 0; i < n; ++i) {
+        const F4 ia = qa, ib = qb;
+        if (i + 1 < n) { qa = ld4(I, (i + 1) * INST_WORDS); qb = ld4(I, (i + 1) * INST_WORDS + 4); }
+        const V3 pos = v3(ia.x, ia.y, ia.z);
+        const u32 tag = f2u(ib.x);
+        const u32 kind = tag & TAG_KIND_MASK;
+        const bool ident = (tag & TAG_IDENT) != 0;
+        const float *X = F + P.off_xf + (tag >> TAG_XF_SHIFT) * XF_WORDS;
+        // Renderer::intersect, src/rt.rs:725-733: n_ray.orig = pos + R*(L*(orig - pos)), n_ray.dir = R*(L*dir)
+        const V3 ro = add(pos, xf_vec(X, ident, sub(ray.o, pos)));
+        const bool fast_d = ident && ray.d_ok;
+        V3 rd = ray.d, m = ray.m;
+        float dd = ray.dd;
+        if (!fast_d) {
+            rd = xf_full(X, ray.d);
+            if constexpr (FEAT & F_BOX) m = recip_patched(rd);
+            dd = dot(rd, rd);
+        }
+        float t0 = 0.0f, t1 = 0.0f;
+        i32 i0 = -1, i1 = -1;
+        bool hit;
+        if (kind == KIND_SPHERE) {
+            hit = sphere_isect(ia.w, sub(ro, pos), rd, dd, t0, t1);
+        } else if (kind == KIND_PLANE) {
+            hit = plane_isect(v3(ib.y, ib.z, ib.w), ia.w, ro, rd, t0);
+            t1 = t0;
+        } else if ((FEAT & F_BOX) && kind == KIND_BOX) {
+            hit = box_isect(v3(ia.w, ib.y, ib.z), ro, m, pos, t0, t1);
+        } else if (FEAT & F_TRI) {
+            const float *R = F + P.off_rend + ldu(F, P.off_instx + i * INSTX_WORDS + INSTX_REND) * REND_WORDS;
+            if (kind == KIND_TRIANGLE) {
                 hit = tri_isect(add(ld3(R, REND_GEO), pos), ld3(R, REND_GEO + 3), ld3(R, REND_GEO + 6), ro, rd, t0);
                 t1 = t0;
-            } else if ((FEAT & F_TRI) && (FEAT & F_BOX) && kind == KIND_MESH) {
+            } else if ((FEAT & F_BOX) && kind == KIND_MESH) {
                 hit = mesh_isect<ANY>(S, ldu(R, REND_GEO), ro, rd, m, pos, t0, i0, t1, i1);
             } else {
                 hit = false;
             }
-            if (hit) {
-                if (ANY) return true;
-                const i32 key = total_key(t0);
-                if (best.rend < 0 || key < best_key) {
-                    best_key = key;
-                    best.rend = (i32)r; best.inst = i; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
-                }
+        } else {
+            hit = false;
+        }
+        if (hit) {
+            if (ANY) return true;
+            const i32 key = total_key(t0);
+            if (best.rend < 0 || key < best_key) {
+                best_key = key;
+                best.rend = 0; best.inst = i; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
             }
         }
     }
-    return best.rend >= 0;
+    if (best.rend < 0) return false;
+    best.rend = (i32)ldu(S.F, P.off_instx + best.inst * INSTX_WORDS + INSTX_REND);
+    return true;
 }
 
 // Object-space image of a world-space hit point, src/rt.rs:782, 798
 struct Obj {
-    const float *R, *I, *X;
+    const float *R, *IX, *X;
     V3 pos;
     bool ident;
     u32 kind;
@@ -355,12 +382,14 @@ struct Obj {
 MRT_HD Obj obj_of(const Scn &S, const Hit &h)
 {
     Obj o;
+    const float *I = S.F + S.P->off_inst + h.inst * INST_WORDS;
+    const u32 tag = ldu(I, INST_TAG);
     o.R = S.F + S.P->off_rend + (u32)h.rend * REND_WORDS;
-    o.I = S.F + S.P->off_inst + h.inst * INST_WORDS;
-    o.X = S.F + S.P->off_xf + ldu(o.I, INST_XF) * XF_WORDS;
-    o.pos = ld3(o.I, INST_POS);
-    o.ident = ldu(o.X, XF_IDENT) != 0;
-    o.kind = ldu(o.R, REND_KIND);
+    o.IX = S.F + S.P->off_instx + h.inst * INSTX_WORDS;
+    o.X = S.F + S.P->off_xf + (tag >> TAG_XF_SHIFT) * XF_WORDS;
+    o.pos = ld3(I, INST_POS);
+    o.ident = (tag & TAG_IDENT) != 0;
+    o.kind = tag & TAG_KIND_MASK;
     return o;
 }
 MRT_HD V3 to_object(const Obj &o, V3 hp) { return add(o.pos, xf_vec(o.X, o.ident, sub(hp, o.pos))); }
@@ -369,7 +398,7 @@ MRT_HD V3 to_object(const Obj &o, V3 hp) { return add(o.pos, xf_vec(o.X, o.ident
 template <u32 FEAT>
 MRT_HD V3 hit_normal(const Scn &S, const Obj &o, V3 n_hit, i32 tri_idx)
 {
-    if (o.kind == KIND_PLANE) return ld3(o.I, INST_PLANE_NW);          // norm(R*(L*n)) is per instance
+    if (o.kind == KIND_PLANE) return ld3(o.IX, INSTX_PLANE_NW);          // norm(R*(L*n)) is per instance
     V3 n = v3(0.0f, 0.0f, 0.0f);
     if (o.kind == KIND_SPHERE) n = sub(n_hit, o.pos);
     else if ((FEAT & F_BOX) && o.kind == KIND_BOX) n = box_normal(ld3(o.R, REND_GEO + 3), n_hit, o.pos);
@@ -481,11 +510,22 @@ MRT_HD void camera_ray(const Params &P, V3 focus, u32 pk, V3 &o, V3 &d)
     const float u2 = u32_to_unit(draw_u32(pk, DIM_LENS_Z));
     const V3 pos = v3(P.cam_pos[0] + (u1 - 0.5f) * P.aprt, P.cam_pos[1], P.cam_pos[2] + (u2 - 0.5f) * P.aprt);
     const V3 new_dir = norm(sub(focus, pos));
-    d = m3mul(P.cam_R, m3mul(P.cam_L, new_dir));
+    // rot_y * (look * new_dir): both matrices are the identity as values for the default camera direction
+    if (P.cam_ident && nzfin3(new_dir)) d = new_dir;
+    else d = m3mul(P.cam_R, m3mul(P.cam_L, new_dir));
     o = add(pos, muls(d, kE));
 }
 
 MRT_HD u32 dim_of(u32 bounce, u32 slot) { return DIM_BOUNCE0 + bounce * DIMS_PER_BOUNCE + slot; }
+
+// Bernoulli draw that only touches the generator when the outcome is open (p == 0 is always false, p == 1 always
+// true: same results as bernoulli(p, draw), fewer hashes)
+MRT_HD bool coin(float p, u32 pk, u32 dim)
+{
+    if (p == 1.0f) return true;
+    if (!(p > 0.0f)) return false;          // p == 0 (or an invalid p, which mrt_create rejects)
+    return draw_u32(pk, dim) < (u32)(p * 4294967296.0f);
+}
 
 // All samples of one supersampled pixel: Sampler::execute's per-pixel body, n_samples times
 // (src/sampler.rs:45-70 calling RayTracer::iter / reduce_light, src/rt.rs:937-994, whose iterator
@@ -495,6 +535,7 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
 {
     const Params &P = *S.P;
     const u32 pixel = y * P.nw + x;
+    const u32 pix_key = mix32(pixel + P.seed_lo) ^ P.seed_hi;      // path_key = mix32(pix_key + sample * kGold)
     const V3 focus = pixel_focus(P, (float)x, (float)y);
     const V3 sky_init = v3(P.sky_init[0], P.sky_init[1], P.sky_init[2]);
 
@@ -509,8 +550,12 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
     for (;;) {
         if (fresh) {
             if (s >= P.n_samples) break;
-            pk = path_key(P.seed_lo, P.seed_hi, pixel, P.sample_base + s);
+            pk = mix32(pix_key + (P.sample_base + s) * kGold);
+#ifdef MRT_ABL_NOREGEN
+            o = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]); d = muls(sub(focus, o), 1.0f / P.foc);
+#else
             camera_ray(P, focus, pk, o, d);
+#endif
             T = v3(1.0f, 1.0f, 1.0f); L = v3(0.0f, 0.0f, 0.0f);
             pwr = 1.0f; b = 0;
             fresh = false;
@@ -533,35 +578,44 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
         const float opacity0 = surf_scalar(S, sf0, MAP_OPACITY, MAT_OPACITY);
         const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
 
-        // 15 % / opacity coin and refraction from the exit hit, src/rt.rs:1051-1059
-        bool refracted = false;
-        V3 nd = v3(0, 0, 0), np = p0;      // next ray direction / the point it leaves from
-        V3 hp = p0, hn = v3(0, 0, 0);      // recorded hit (n_hit): point and normal
-        Surf sfh = sf0;
-        if (bernoulli(fmin_(1.0f - opacity0, 0.85f), draw_u32(pk, dim_of(b, SL_OPAC_COIN)))) {
-            const V3 p1 = add(o, muls(d, h.t1));
-            const V3 nh1 = to_object(ob, p1);
-            const V3 n1 = hit_normal<FEAT>(S, ob, nh1, h.i1);
-            const Surf sf1 = surf_of<FEAT>(S, h, ob, nh1);
-            float rough = surf_scalar(S, sf1, MAP_ROUGH, MAT_ROUGH);      // Ray::refract, src/rt.rs:574-589
-            const float opac1 = surf_scalar(S, sf1, MAP_OPACITY, MAT_OPACITY);
-            if (metal_c == 0.0f && opac1 != 0.0f && bernoulli(0.80f, draw_u32(pk, dim_of(b, SL_REFR_COIN)))) rough = 1.0f;
-            const V3 nn = rand_normal(n1, rough, u32_to_unit(draw_u32(pk, dim_of(b, SL_REFR_U1))), u32_to_unit(draw_u32(pk, dim_of(b, SL_REFR_U2))));
-            const float eta = 1.0f + 0.5f * surf_scalar(S, sf1, MAP_GLASS, MAT_GLASS);
-            V3 rdir;
-            if (refract(d, eta, nn, rdir)) {
-                refracted = true;
-                nd = norm(rdir); np = p1;
-                hp = p1; hn = n1; sfh = sf1;
+        // Scatter.  The reference always builds the reflected ray at hit0 (src/rt.rs:1049) and replaces it by the
+        // refracted ray from the exit hit when the 15 % / opacity coin comes up and refraction is possible
+        // (src/rt.rs:1054-1058).  Draws are slot-addressed, so only the ray that survives is computed: lanes that
+        // try to refract and lanes that reflect share one pass through the normal / perturbation code; a failed
+        // refraction (total internal reflection) takes a second pass as a reflection.
+        bool refr = coin(fmin_(1.0f - opacity0, 0.85f), pk, dim_of(b, SL_OPAC_COIN));
+        V3 nd, hp, hn;
+        Surf sfh;
+        for (;;) {
+            hp = refr ? add(o, muls(d, h.t1)) : p0;                 // recorded hit point: hit.1 or hit.0
+            const V3 nhh = refr ? to_object(ob, hp) : nh0;
+            hn = hit_normal<FEAT>(S, ob, nhh, refr ? h.i1 : h.i0);
+            sfh = sf0;
+            if (refr) sfh = surf_of<FEAT>(S, h, ob, nhh);
+            float rough = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);            // Ray::reflect / Ray::refract, src/rt.rs:559-589
+            const float opac = refr ? surf_scalar(S, sfh, MAP_OPACITY, MAT_OPACITY) : opacity0;
+            const u32 base = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);     // coin, u1, u2 are consecutive slots
+            if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, base) < (u32)(0.80f * 4294967296.0f)) rough = 1.0f;
+#ifdef MRT_ABL_NOSCATTER
+            const V3 nn = norm(add(hn, muls(d, rough * 0.01f)));
+#else
+            const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, base + 1u)), u32_to_unit(draw_u32(pk, base + 2u)));
+#endif
+            if (refr) {
+                const float eta = 1.0f + 0.5f * surf_scalar(S, sfh, MAP_GLASS, MAT_GLASS);
+                V3 rdir;
+                if (refract(d, eta, nn, rdir)) { nd = norm(rdir); break; }
+                refr = false;                                       // Vec3f::refract returned None
+                continue;
             }
+            nd = norm(reflect(d, nn));
+            break;
         }
-        if (!refracted) hn = hit_normal<FEAT>(S, ob, nh0, h.i0);
-        const V3 n0 = hn;   // when not refracted this is hit0's normal (used by reflect below)
 
         // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
         const V3 color = surf_color(S, sfh);
         const float emit = surf_scalar(S, sfh, MAP_EMIT, MAT_EMIT);
-        if (bernoulli(emit, draw_u32(pk, dim_of(b, SL_EMIT_COIN)))) {
+        if (coin(emit, pk, dim_of(b, SL_EMIT_COIN))) {
             acc = add(acc, add(L, hadam(T, color)));
             ++s; fresh = true;
             continue;
@@ -592,20 +646,12 @@ MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
             }
         }
 
-        // Ray::reflect at hit0, src/rt.rs:559-572 (skipped when the refracted ray replaced it)
-        if (!refracted) {
-            float rough = surf_scalar(S, sf0, MAP_ROUGH, MAT_ROUGH);
-            if (metal_c == 0.0f && opacity0 != 0.0f && bernoulli(0.80f, draw_u32(pk, dim_of(b, SL_REFL_COIN)))) rough = 1.0f;
-            const V3 nn = rand_normal(n0, rough, u32_to_unit(draw_u32(pk, dim_of(b, SL_REFL_U1))), u32_to_unit(draw_u32(pk, dim_of(b, SL_REFL_U2))));
-            nd = norm(reflect(d, nn));
-        }
-
         // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
         L = add(L, hadam(T, muls(l_col, pwr)));
         T = hadam(T, muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr));
 
         // Ray::cast, src/rt.rs:551-553, 571
-        o = add(np, muls(nd, kE));
+        o = add(hp, muls(nd, kE));
         d = nd;
         pwr = pwr * P.q;
         ++b;

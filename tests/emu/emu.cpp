@@ -49,6 +49,7 @@ int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, ui
     if (row1 > pk.nh) row1 = pk.nh;
     Scn S;
     S.F = reinterpret_cast<const float *>(pk.blob.data());
+    S.U = S.F;
     S.P = &P;
     std::atomic<uint32_t> next(row0);
     std::atomic<uint64_t> segs(0);
