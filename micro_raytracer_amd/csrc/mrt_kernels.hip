@@ -24,12 +24,20 @@ namespace mrt {
 // VALU-issue bound, so the light variants (planes / spheres / boxes, no maps, no lights, no triangles) are squeezed to
 // 6 waves per SIMD (80 VGPRs, a few spills: measured +14 % on the Cornell box); the heavier variants lose more to
 // spills than they gain from occupancy and keep the compiler's choice.  MRT_WAVES_PER_EU overrides (experiments).
+constexpr bool lds_stash_for(u32 feat)
+{
+#ifdef MRT_NO_STASH
+    return false;
+#else
+    return (feat & ~F_BOX) == 0;
+#endif
+}
 constexpr int waves_for(u32 feat)
 {
 #ifdef MRT_WAVES_PER_EU
     return MRT_WAVES_PER_EU;
 #else
-    return (feat & ~F_BOX) == 0 ? 6 : 2;
+    return feat == 0 ? 6 : (feat == F_BOX ? 5 : 2);
 #endif
 }
 
@@ -69,7 +77,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         S.P = &P;
         float *px = P.accum + ((size_t)ry * P.nw + x) * 3u;
         V3 acc = v3(px[0], px[1], px[2]);
-        render_pixel<FEAT>(S, x, y, acc, segments);
+        if constexpr (lds_stash_for(FEAT)) {
+            // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
+            LdsStash st;
+            static_assert(BLOCK_THREADS == 256 || !lds_stash_for(FEAT), "the LDS stash is laid out for 256 threads");
+            st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + ((P.blob_words + 3u) >> 2)) + threadIdx.x);
+            render_pixel<FEAT>(S, st, x, y, acc, segments);
+        } else {
+            RegStash st;
+            render_pixel<FEAT>(S, st, x, y, acc, segments);
+        }
         px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
     }
     if (P.count_segments) {
@@ -168,8 +185,9 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     if (block_threads != P.tiles_x * P.tiles_y * 64u || (block_threads != 256u && block_threads != 512u)) return hipErrorInvalidConfiguration;
     const u32 tile_w = P.tiles_x * 8u, tile_h = P.tiles_y * 8u;
     dim3 grid((P.nw + tile_w - 1) / tile_w, (P.local_rows + tile_h - 1) / tile_h);
-    const size_t lds = scene_in_lds ? (size_t)P.blob_words * 4u : 0;
+    size_t lds = scene_in_lds ? (size_t)P.blob_words * 4u : 0;
     if (scene_in_lds) {
+        if (block_threads == 256u && lds_stash_for(features & F_ALL)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * 256u * sizeof(float);
         if (block_threads == 256u) kLds256[features & F_ALL](grid, lds, stream, P);
         else hipLaunchKernelGGL((pt_megakernel<true, 512, F_ALL>), grid, dim3(512), lds, stream, P, P.blob);
     } else {

@@ -26,6 +26,12 @@ enum : u32 {
     F_ALL = 15u
 };
 
+// Divergence probe: only the x86 build of tests/emu defines MRT_PROBE(phase); in the kernel it is nothing.
+#ifndef MRT_PROBE
+#define MRT_PROBE(phase)
+#endif
+enum : u32 { PH_ITER = 0, PH_REGEN, PH_SPHERE_MATH, PH_PLANE_HIT, PH_SHADE, PH_NORMAL_NONPLANE, PH_SCATTER1, PH_SCATTER2, PH_REFRACT, PH_EMIT_END, PH_LIGHTS, PH_COUNT };
+
 constexpr float kE = 0.0001f;                 // src/rt.rs:7
 constexpr float kBig = 1.0f / 0.0001f;        // E.recip(), src/rt.rs:307
 
@@ -105,9 +111,7 @@ MRT_HD bool sphere_isect(float r2, V3 oo, V3 rd, float a, float &t0, float &t1)
     // NaN, and with b > 1e-20 and 0 < a < 1e18 the quotient is a non-zero negative number (no underflow to -0,
     // which the reference would accept as a hit at t0 = -0).
     if (b > 1e-20f && a > 0.0f && a < 1e18f && disc >= 0.0f) return false;
-#ifdef MRT_ABL_NOSPHEREMATH
-    t0 = -b * 0.5f; t1 = t0; return t0 > 0.0f;
-#endif
+    MRT_PROBE(PH_SPHERE_MATH);
     const float sq = sqrt_(disc);
     const float q0 = (-b - sq) / (2.0f * a);
     if (q0 < 0.0f) return false;
@@ -138,11 +142,7 @@ MRT_HD bool tri_isect(V3 vp, V3 e0, V3 e1, V3 ro, V3 rd, float &t)
 // Plane::intersect, src/rt.rs:400-412; nn = norm(n), d = (-nn).pos
 MRT_HD bool plane_isect(V3 nn, float d, V3 ro, V3 rd, float &t)
 {
-#ifdef MRT_ABL_NODIV
-    const float tt = -(dot(ro, nn) + d) * __builtin_amdgcn_rcpf(dot(rd, nn));
-#else
     const float tt = -(dot(ro, nn) + d) / dot(rd, nn);
-#endif
     if (tt <= 0.0f) return false;
     t = tt;
     return true;
@@ -516,6 +516,17 @@ MRT_HD void camera_ray(const Params &P, V3 focus, u32 pk, V3 &o, V3 &d)
     o = add(pos, muls(d, kE));
 }
 
+// hides a value from the optimiser (see the loop in render_pixel)
+MRT_HD u32 opaque(u32 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#else
+    asm volatile("" : "+r"(x));
+#endif
+    return x;
+}
+
 MRT_HD u32 dim_of(u32 bounce, u32 slot) { return DIM_BOUNCE0 + bounce * DIMS_PER_BOUNCE + slot; }
 
 // Bernoulli draw that only touches the generator when the outcome is open (p == 0 is always false, p == 1 always
@@ -527,139 +538,172 @@ MRT_HD bool coin(float p, u32 pk, u32 dim)
     return draw_u32(pk, dim) < (u32)(p * 4294967296.0f);
 }
 
+// Per-lane state that is only touched between segments (path radiance, throughput, the pixel's accumulator and
+// camera focus point).  RegStash keeps it in registers; LdsStash parks it in a per-lane LDS column (slot-major, so
+// lane i always hits bank i) to free VGPRs for the traversal loop without the compiler spilling to scratch,
+// whose write-backs would show up as HBM traffic.  volatile: the values must really live in LDS across the loop.
+enum : u32 { ST_ACC = 0, ST_FOCUS = 3, ST_SLOTS = 6 };
+struct RegStash {
+    float v[ST_SLOTS];
+    MRT_HD void put(u32 slot, float x) { v[slot] = x; }
+    MRT_HD float get(u32 slot) const { return v[slot]; }
+};
+#if defined(__HIPCC__) || defined(__HIP__)
+typedef __attribute__((address_space(3))) volatile float lds_vfloat;   // keeps ds_read / ds_write addressing
+struct LdsStash {
+    lds_vfloat *base;         // &lds_stash[tid]
+    MRT_HD void put(u32 slot, float x) { base[slot * 256u] = x; }      // 256-thread workgroups only
+    MRT_HD float get(u32 slot) const { return base[slot * 256u]; }
+};
+#endif
+template <class St> MRT_HD void st_put3(St &st, u32 slot, V3 v) { st.put(slot, v.x); st.put(slot + 1, v.y); st.put(slot + 2, v.z); }
+template <class St> MRT_HD V3 st_get3(const St &st, u32 slot) { return v3(st.get(slot), st.get(slot + 1), st.get(slot + 2)); }
+
 // All samples of one supersampled pixel: Sampler::execute's per-pixel body, n_samples times
 // (src/sampler.rs:45-70 calling RayTracer::iter / reduce_light, src/rt.rs:937-994, whose iterator
 // is RaytraceIterator::next, src/rt.rs:1014-1066).  acc is the running colors[(x, y)] entry.
-template <u32 FEAT>
-MRT_HD void render_pixel(const Scn &S, u32 x, u32 y, V3 &acc, u32 &segments)
+template <u32 FEAT, class Stash>
+MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, V3 &acc_io, u32 &segments)
 {
     const Params &P = *S.P;
     const u32 pixel = y * P.nw + x;
     const u32 pix_key = mix32(pixel + P.seed_lo) ^ P.seed_hi;      // path_key = mix32(pix_key + sample * kGold)
-    const V3 focus = pixel_focus(P, (float)x, (float)y);
     const V3 sky_init = v3(P.sky_init[0], P.sky_init[1], P.sky_init[2]);
+    st_put3(st, ST_ACC, acc_io);
+    st_put3(st, ST_FOCUS, pixel_focus(P, (float)x, (float)y));
 
     u32 s = 0;
-    bool fresh = true;
+    u32 fresh = 1;
     u32 pk = 0, b = 0;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
     V3 T = v3(1, 1, 1), L = v3(0, 0, 0);
     float pwr = 1.0f;
     u32 seg = 0;
 
+    // ONE loop with ONE back-edge: a lane whose path ended regenerates at the top of the very next iteration while
+    // its neighbours keep tracing.  (With `continue`s the optimiser threads the known value of `fresh` through the
+    // back-edges and splits this into an outer regeneration loop around an inner segment loop; a wavefront then only
+    // regenerates once all 64 paths have ended.  opaque() hides the value and keeps the loop flat.)
     for (;;) {
+        MRT_PROBE(PH_ITER);
         if (fresh) {
             if (s >= P.n_samples) break;
+            MRT_PROBE(PH_REGEN);
             pk = mix32(pix_key + (P.sample_base + s) * kGold);
-#ifdef MRT_ABL_NOREGEN
-            o = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]); d = muls(sub(focus, o), 1.0f / P.foc);
-#else
-            camera_ray(P, focus, pk, o, d);
-#endif
+            camera_ray(P, st_get3(st, ST_FOCUS), pk, o, d);
             T = v3(1.0f, 1.0f, 1.0f); L = v3(0.0f, 0.0f, 0.0f);
             pwr = 1.0f; b = 0;
-            fresh = false;
+            fresh = 0;
         }
         // ---- RaytraceIterator::next ----
         const RayPre ray = ray_pre<FEAT>(o, d);
         Hit h;
         ++seg;
+        V3 contrib = v3(0.0f, 0.0f, 0.0f);
+        bool ended = false;
         if (!trace<false, FEAT>(S, ray, h)) {
             // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
-            const V3 c = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
-            acc = add(acc, c);
-            ++s; fresh = true;
-            continue;
-        }
-        const Obj ob = obj_of(S, h);
-        const V3 p0 = add(o, muls(d, h.t0));                       // Vec3f::from(&hit.0.ray)
-        const V3 nh0 = to_object(ob, p0);
-        const Surf sf0 = surf_of<FEAT>(S, h, ob, nh0);
-        const float opacity0 = surf_scalar(S, sf0, MAP_OPACITY, MAT_OPACITY);
-        const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
+            contrib = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
+            ended = true;
+        } else {
+            MRT_PROBE(PH_SHADE);
+            const Obj ob = obj_of(S, h);
+            const V3 p0 = add(o, muls(d, h.t0));                       // Vec3f::from(&hit.0.ray)
+            const V3 nh0 = to_object(ob, p0);
+            const Surf sf0 = surf_of<FEAT>(S, h, ob, nh0);
+            const float opacity0 = surf_scalar(S, sf0, MAP_OPACITY, MAT_OPACITY);
+            const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
 
-        // Scatter.  The reference always builds the reflected ray at hit0 (src/rt.rs:1049) and replaces it by the
-        // refracted ray from the exit hit when the 15 % / opacity coin comes up and refraction is possible
-        // (src/rt.rs:1054-1058).  Draws are slot-addressed, so only the ray that survives is computed: lanes that
-        // try to refract and lanes that reflect share one pass through the normal / perturbation code; a failed
-        // refraction (total internal reflection) takes a second pass as a reflection.
-        bool refr = coin(fmin_(1.0f - opacity0, 0.85f), pk, dim_of(b, SL_OPAC_COIN));
-        V3 nd, hp, hn;
-        Surf sfh;
-        for (;;) {
-            hp = refr ? add(o, muls(d, h.t1)) : p0;                 // recorded hit point: hit.1 or hit.0
-            const V3 nhh = refr ? to_object(ob, hp) : nh0;
-            hn = hit_normal<FEAT>(S, ob, nhh, refr ? h.i1 : h.i0);
-            sfh = sf0;
-            if (refr) sfh = surf_of<FEAT>(S, h, ob, nhh);
-            float rough = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);            // Ray::reflect / Ray::refract, src/rt.rs:559-589
-            const float opac = refr ? surf_scalar(S, sfh, MAP_OPACITY, MAT_OPACITY) : opacity0;
-            const u32 base = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);     // coin, u1, u2 are consecutive slots
-            if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, base) < (u32)(0.80f * 4294967296.0f)) rough = 1.0f;
-#ifdef MRT_ABL_NOSCATTER
-            const V3 nn = norm(add(hn, muls(d, rough * 0.01f)));
-#else
-            const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, base + 1u)), u32_to_unit(draw_u32(pk, base + 2u)));
-#endif
-            if (refr) {
-                const float eta = 1.0f + 0.5f * surf_scalar(S, sfh, MAP_GLASS, MAT_GLASS);
-                V3 rdir;
-                if (refract(d, eta, nn, rdir)) { nd = norm(rdir); break; }
-                refr = false;                                       // Vec3f::refract returned None
-                continue;
+            // Scatter.  The reference always builds the reflected ray at hit0 (src/rt.rs:1049) and replaces it by the
+            // refracted ray from the exit hit when the 15 % / opacity coin comes up and refraction is possible
+            // (src/rt.rs:1054-1058).  Draws are slot-addressed, so only the ray that survives is computed: lanes that
+            // try to refract and lanes that reflect share one pass through the normal / perturbation code; a failed
+            // refraction (total internal reflection) takes a second pass as a reflection.
+            bool refr = coin(fmin_(1.0f - opacity0, 0.85f), pk, dim_of(b, SL_OPAC_COIN));
+            V3 nd, hp, hn;
+            Surf sfh;
+            u32 pass = 0;
+            for (;;) {
+                if (pass == 0) { MRT_PROBE(PH_SCATTER1); } else { MRT_PROBE(PH_SCATTER2); }
+                ++pass;
+                if (refr) { MRT_PROBE(PH_REFRACT); }
+                if (ob.kind != KIND_PLANE) { MRT_PROBE(PH_NORMAL_NONPLANE); }
+                hp = refr ? add(o, muls(d, h.t1)) : p0;                 // recorded hit point: hit.1 or hit.0
+                const V3 nhh = refr ? to_object(ob, hp) : nh0;
+                hn = hit_normal<FEAT>(S, ob, nhh, refr ? h.i1 : h.i0);
+                sfh = sf0;
+                if (refr) sfh = surf_of<FEAT>(S, h, ob, nhh);
+                float rough = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);            // Ray::reflect / Ray::refract, src/rt.rs:559-589
+                const float opac = refr ? surf_scalar(S, sfh, MAP_OPACITY, MAT_OPACITY) : opacity0;
+                const u32 base = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);     // coin, u1, u2 are consecutive slots
+                if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, base) < (u32)(0.80f * 4294967296.0f)) rough = 1.0f;
+                const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, base + 1u)), u32_to_unit(draw_u32(pk, base + 2u)));
+                if (refr) {
+                    const float eta = 1.0f + 0.5f * surf_scalar(S, sfh, MAP_GLASS, MAT_GLASS);
+                    V3 rdir;
+                    if (refract(d, eta, nn, rdir)) { nd = norm(rdir); break; }
+                    refr = false;                                       // Vec3f::refract returned None
+                    continue;
+                }
+                nd = norm(reflect(d, nn));
+                break;
             }
-            nd = norm(reflect(d, nn));
-            break;
-        }
 
-        // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
-        const V3 color = surf_color(S, sfh);
-        const float emit = surf_scalar(S, sfh, MAP_EMIT, MAT_EMIT);
-        if (coin(emit, pk, dim_of(b, SL_EMIT_COIN))) {
-            acc = add(acc, add(L, hadam(T, color)));
-            ++s; fresh = true;
-            continue;
-        }
+            // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
+            const V3 color = surf_color(S, sfh);
+            const float emit = surf_scalar(S, sfh, MAP_EMIT, MAT_EMIT);
+            if (coin(emit, pk, dim_of(b, SL_EMIT_COIN))) {
+                MRT_PROBE(PH_EMIT_END);
+                contrib = add(L, hadam(T, color));
+                ended = true;
+            } else {
+                // direct light, visibility from hit0 (src/rt.rs:1027-1046), shading at the recorded hit (:973-987)
+                if ((FEAT & F_LIGHTS) && P.n_light) {
+                    V3 l_col = v3(0.0f, 0.0f, 0.0f);
+                    const float rough_h = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);
+                    const float metal_h = surf_scalar(S, sfh, MAP_METAL, MAT_METAL);
+                    for (u32 li = 0; li < P.n_light; ++li) {
+                        const float *Lt = S.F + P.off_light + li * LIGHT_WORDS;
+                        const bool point = ldu(Lt, LIGHT_KIND) == LK_POINT;
+                        const V3 lv = ld3(Lt, LIGHT_V);
+                        const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
+                        const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
+                        Hit hs;
+                        if (trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs)) continue;
+                        const V3 ln = point ? norm(sub(lv, hp)) : lv;             // l.norm() at the recorded hit
+                        const float diff = fmax_(dot(ln, hn), 0.0f);
+                        const float sp = fmax_(dot(d, reflect(ln, hn)), 0.0f);
+                        const float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16;   // powi(32)
+                        const float spec = s32 * (1.0f - rough_h);
+                        const V3 o_col = muls(color, 1.0f - metal_h);
+                        V3 t = hadam(muls(o_col, diff), ld3(Lt, LIGHT_COLOR));
+                        t = v3(t.x + spec, t.y + spec, t.z + spec);
+                        l_col = add(l_col, muls(t, Lt[LIGHT_PWR]));
+                    }
+                    // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
+                    L = add(L, hadam(T, muls(l_col, pwr)));
+                }
+                T = hadam(T, muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr));
 
-        // direct light, visibility from hit0 (src/rt.rs:1027-1046), shading at the recorded hit (:973-987)
-        V3 l_col = v3(0.0f, 0.0f, 0.0f);
-        if ((FEAT & F_LIGHTS) && P.n_light) {
-            const float rough_h = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);
-            const float metal_h = surf_scalar(S, sfh, MAP_METAL, MAT_METAL);
-            for (u32 li = 0; li < P.n_light; ++li) {
-                const float *Lt = S.F + P.off_light + li * LIGHT_WORDS;
-                const bool point = ldu(Lt, LIGHT_KIND) == LK_POINT;
-                const V3 lv = ld3(Lt, LIGHT_V);
-                const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
-                const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
-                Hit hs;
-                if (trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs)) continue;
-                const V3 ln = point ? norm(sub(lv, hp)) : lv;             // l.norm() at the recorded hit
-                const float diff = fmax_(dot(ln, hn), 0.0f);
-                const float sp = fmax_(dot(d, reflect(ln, hn)), 0.0f);
-                const float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16;   // powi(32)
-                const float spec = s32 * (1.0f - rough_h);
-                const V3 o_col = muls(color, 1.0f - metal_h);
-                V3 t = hadam(muls(o_col, diff), ld3(Lt, LIGHT_COLOR));
-                t = v3(t.x + spec, t.y + spec, t.z + spec);
-                l_col = add(l_col, muls(t, Lt[LIGHT_PWR]));
+                // Ray::cast, src/rt.rs:551-553, 571
+                o = add(hp, muls(nd, kE));
+                d = nd;
+                pwr = pwr * P.q;
+                ++b;
+                if (b > P.bounce) {          // src/rt.rs:1018
+                    contrib = add(L, hadam(T, sky_init));
+                    ended = true;
+                }
             }
         }
-
-        // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
-        L = add(L, hadam(T, muls(l_col, pwr)));
-        T = hadam(T, muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr));
-
-        // Ray::cast, src/rt.rs:551-553, 571
-        o = add(hp, muls(nd, kE));
-        d = nd;
-        pwr = pwr * P.q;
-        ++b;
-        if (b > P.bounce) {          // src/rt.rs:1018
-            acc = add(acc, add(L, hadam(T, sky_init)));
-            ++s; fresh = true;
+        if (ended) {
+            st_put3(st, ST_ACC, add(st_get3(st, ST_ACC), contrib));
+            ++s;
+            fresh = 1;
         }
+        fresh = opaque(fresh);
     }
+    acc_io = st_get3(st, ST_ACC);
     segments = seg;
 }
 

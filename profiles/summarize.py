@@ -1,0 +1,46 @@
+"""Summarise rocprofv3 outputs (gpurun_out/<tag>_{trace,pmc_*}) into profiles/<tag>_* files.
+usage: python profiles/summarize.py r1b"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag = sys.argv[1]
+out = {}
+ks = glob.glob(f"gpurun_out/{tag}_trace/*/*_kernel_stats.csv")
+if ks:
+    shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
+    for r in csv.DictReader(open(ks[0])):
+        if "pt_megakernel" in r["Name"]:
+            out["kernel"] = r["Name"]
+            out["calls"] = int(r["Calls"])
+            out["avg_ms"] = float(r["AverageNs"]) / 1e6
+            out["pct_gpu_time"] = float(r["Percentage"])
+pmc = collections.defaultdict(float)
+meta = {}
+for f in glob.glob(f"gpurun_out/{tag}_pmc_*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "pt_megakernel" in r["Kernel_Name"]:
+            pmc[r["Counter_Name"]] += float(r["Counter_Value"])
+            meta = {k: r[k] for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
+out["pmc_per_launch"] = dict(pmc)
+out["dispatch"] = meta
+d = {}
+if "SQ_INSTS_VALU" in pmc:
+    d["valu_wave_instr"] = pmc["SQ_INSTS_VALU"]
+    d["lane_utilisation"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc:
+    d["wait_any_frac"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
+    d["wait_inst_any_frac"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
+    d["active_inst_any_frac"] = pmc["SQ_ACTIVE_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    # MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B; on gfx950 FETCH_SIZE reads half
+    # the bytes of a coalesced streaming read -> doubled; WRITE_SIZE is exact.  Separate --pmc passes.
+    d["hbm_read_bytes"] = 2.0 * pmc["FETCH_SIZE"] * 1024.0
+    d["hbm_write_bytes"] = pmc["WRITE_SIZE"] * 1024.0
+    d["hbm_traffic_bytes"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
+out["derived"] = d
+json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -64,7 +64,7 @@ int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, ui
                 float *px = accum + ((size_t)y * pk.nw + x) * 3;
                 V3 acc = v3(px[0], px[1], px[2]);
                 u32 sg = 0;
-                render_pixel<F_ALL>(S, x, y, acc, sg);
+                { RegStash st; render_pixel<F_ALL>(S, st, x, y, acc, sg); }
                 px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
                 local += sg;
             }

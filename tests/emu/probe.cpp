@@ -1,0 +1,49 @@
+// probe.cpp — TEST INFRASTRUCTURE: divergence profile of the megakernel's per-lane loop, computed on the CPU.
+// Every lane's loop iterations line up in lock-step inside a wavefront (the loop has one back-edge), so recording
+// per lane which phases ran in its k-th iteration tells, per 8x8 wave tile, how many lanes were active whenever the
+// wavefront had to execute a phase.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static thread_local std::vector<uint16_t> *g_rec = nullptr;   // one bitmask per iteration
+#define MRT_PROBE(phase) do { if (g_rec) { if ((phase) == 0) g_rec->push_back(1); else g_rec->back() |= (uint16_t)(1u << (phase)); } } while (0)
+
+#include "../../micro_raytracer_amd/csrc/mrt_pack.h"
+#include "../../micro_raytracer_amd/csrc/mrt_trace.h"
+using namespace mrt;
+
+extern "C" int probe_divergence(const mrt_render_desc *d, uint64_t seed, uint32_t n_samples, uint32_t tile_x0, uint32_t tile_y0,
+                                uint32_t tiles_x, uint32_t tiles_y, double *active /*[PH_COUNT]*/, double *executed /*[PH_COUNT]*/)
+{
+    Packed pk; std::string err;
+    if (pack_scene(d, pk, err)) return -1;
+    Params P = pk.P;
+    P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
+    P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.n_samples = n_samples; P.sample_base = 0;
+    Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.P = &P;
+    for (u32 p = 0; p < PH_COUNT; ++p) { active[p] = 0; executed[p] = 0; }
+    for (uint32_t ty = tile_y0; ty < tile_y0 + tiles_y; ++ty)
+        for (uint32_t tx = tile_x0; tx < tile_x0 + tiles_x; ++tx) {
+            std::vector<std::vector<uint16_t>> rec(64);
+            size_t max_it = 0;
+            for (int l = 0; l < 64; ++l) {
+                const uint32_t x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
+                if (x >= pk.nw || y >= pk.nh) continue;
+                g_rec = &rec[l];
+                V3 acc = v3(0, 0, 0); u32 sg = 0; RegStash st;
+                render_pixel<F_ALL>(S, st, x, y, acc, sg);
+                g_rec = nullptr;
+                if (rec[l].size() > max_it) max_it = rec[l].size();
+            }
+            for (size_t k = 0; k < max_it; ++k)
+                for (u32 p = 0; p < PH_COUNT; ++p) {
+                    int n = 0;
+                    for (int l = 0; l < 64; ++l) if (k < rec[l].size() && (rec[l][k] >> p & 1)) ++n;
+                    if (n) { active[p] += n; executed[p] += 64; }
+                }
+        }
+    return 0;
+}
