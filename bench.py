@@ -63,6 +63,22 @@ def cpu_baseline(render, seconds_target=15.0):
             "sample": f"rows {rows[0]}..{rows[1]} of the {nw}x{nh} frame, {spp2} spp, {t2:.1f} s"}
 
 
+def pmc_traffic(workload, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_summary.json, written by profiles/summarize.py: FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md, WRITE_SIZE as is, separate --pmc passes).  None when no matching profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("n_gpus", 1) == world and "hbm_traffic_bytes" in d.get("derived", {}):
+            best = (d["derived"]["hbm_traffic_bytes"], os.path.basename(f))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,7 +160,8 @@ def main():
                        "bounce": render.rt.bounce, "samples_per_step": float(nw) * nh * spp,
                        "sharding": f"rows, block-cyclic x{ss.shard_rows}, {world} rank(s), 1 RCCL gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "pt_megakernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": (pmc_traffic(args.workload, world) or (None, None))[0] if not args.spp else None,
+                         "traffic_source": (pmc_traffic(args.workload, world) or (None, None))[1] if not args.spp else None, "kernel": "pt_megakernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "by construction not HBM-bound (SURVEY.md §8d): the scene lives in LDS, HBM sees 24 B per pixel per launch"},
             "valu": {"achieved_tflops": valu_tflops, "peak_tflops": VALU_PEAK_TFLOPS, "frac": valu_tflops / VALU_PEAK_TFLOPS,
                      "segments_per_sample": total_segments / samples, "flop_per_segment_model": FLOP_PER_SEGMENT,

@@ -8,7 +8,8 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-out = {}
+out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "cornell_1080p_1024spp_b8", "n_gpus": 1,
+       "command": "python3 bench.py --no-cpu-baseline (trace) / --steps 1 --warmup 0 (pmc passes)"}
 ks = glob.glob(f"gpurun_out/{tag}_trace/*/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")

@@ -1,0 +1,81 @@
+"""Properties at BASELINE.json's full sizes, where the oracle is too slow for a whole-frame comparison:
+determinism, independence of batching and of the shard count, and oracle parity on a band of rows."""
+import numpy as np
+import pytest
+
+from conftest import make_holder
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(render, spp, seed=9, chunks=None, **kw):
+    from micro_raytracer_amd import Sampler
+    s = Sampler(seed=seed, **kw)
+    for n in (chunks or [spp]):
+        s.execute(render, n_samples=n)
+    return s
+
+
+def test_c2_cornell_512x512x64_determinism_batching_shards_and_band_parity(oracle_mod):
+    """BASELINE.json configs[1]: CornellBox 512x512, 64 spp, 8 bounces."""
+    from micro_raytracer_amd import scenes
+    render, holder = make_holder(scenes.cornell_box(res=(512, 512), sample=64, bounce=8))
+    a, ca = _render(render, 64).accum()
+    b, cb = _render(render, 64).accum()
+    assert ca == cb == 64 and np.array_equal(a, b)                         # deterministic
+    c, _ = _render(render, 64, chunks=[1, 7, 24, 32]).accum()
+    assert np.array_equal(a, c)                                            # independent of batching
+    whole = np.zeros_like(a)
+    for r in range(4):                                                     # 4 row shards == 1 context
+        loc, rows = _render(render, 64, shard_index=r, shard_count=4).accum_local()
+        whole[rows] = loc
+    assert np.array_equal(a, whole)
+    assert np.isfinite(a).all() and a.min() >= 0.0
+    mean = a / 64
+    assert 0.005 < mean.mean() < 0.2                                       # closed box lit by one emissive sphere
+    o = oracle_mod.Oracle(holder, seed=9)                                  # oracle on an 8-row band through the spheres
+    o.execute(64, rows=(296, 304))
+    ref, _ = o.accum()
+    err = np.abs(a[296:304] - ref[296:304]).max() / 64
+    print(f"C2 band L-inf {err:.3e}")
+    assert err <= 1e-4
+
+
+def test_c3_cornellbox2_3840x2160_ssaa2_shards_and_band_parity(oracle_mod):
+    """BASELINE.json configs[2]/[3] geometry at full supersampled size (1920x1080 ssaa 2 = 3840x2160), bounce 16,
+    few samples: 8-way row shards reassemble the single-context frame; oracle parity on a band; img runs."""
+    from micro_raytracer_amd import scenes
+    render, holder = make_holder(scenes.cornell_box2(res=(1920, 1080), ssaa=2, sample=2, bounce=16))
+    s = _render(render, 2)
+    a, _ = s.accum()
+    assert a.shape == (2160, 3840, 3)
+    whole = np.zeros_like(a)
+    for r in range(8):
+        loc, rows = _render(render, 2, shard_index=r, shard_count=8).accum_local()
+        whole[rows] = loc
+    assert np.array_equal(a, whole)
+    o = oracle_mod.Oracle(holder, seed=9)
+    o.execute(2, rows=(1400, 1404))
+    ref, _ = o.accum()
+    err = np.abs(a[1400:1404] - ref[1400:1404]).max() / 2
+    print(f"C3 band L-inf {err:.3e}")
+    assert err <= 1e-4
+    img = s.img()
+    assert img.shape == (1080, 1920, 3) and img.dtype == np.uint8
+    # resize of the GPU image == oracle's Lanczos3 of the GPU's tone-mapped frame (bytes)
+    assert np.array_equal(img, oracle_mod.lanczos3_resize(s.img_ss(), 1920, 1080))
+
+
+def test_c5_mesh_and_minecraft_shapes_band_parity(oracle_mod):
+    """BASELINE.json configs[4]: triangle-heavy / textured scenes at 1920x1080 (1 spp), parity on a band."""
+    from micro_raytracer_amd import scenes
+    for name, desc, band in (("mesh", scenes.mesh_scene(res=(1920, 1080), sample=1), (500, 504)),
+                             ("minecraft", scenes.minecraft_like(res=(1920, 1080), ssaa=2, sample=1), (1300, 1302))):
+        render, holder = make_holder(desc)
+        a, _ = _render(render, 1).accum()
+        o = oracle_mod.Oracle(holder, seed=9)
+        o.execute(1, rows=band)
+        ref, _ = o.accum()
+        err = np.nanmax(np.abs(a[band[0]:band[1]] - ref[band[0]:band[1]]))
+        print(f"C5 {name} band L-inf {err:.3e}")
+        assert err <= 1e-4
