@@ -99,10 +99,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the backend has no CPU path)")
+    # MRT_DIST_BACKEND=gloo + MRT_SHARE_DEVICE=1 rehearse the N > 1 path on a one-GPU box (all ranks on device 0,
+    # the gather staged through host memory); the default is RCCL with one device per rank.
+    backend = os.environ.get("MRT_DIST_BACKEND", "nccl")
+    if os.environ.get("MRT_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from micro_raytracer_amd.dist import ShardedSampler
 
@@ -114,6 +122,7 @@ def main():
     nw, nh = ss.nw, ss.nh
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -131,10 +140,11 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        seg_t = torch.tensor([float(segments)], dtype=torch.float64, device="cuda")
+        seg_t = torch.tensor([float(segments)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
         total_segments = float(seg_t.item())
     else:

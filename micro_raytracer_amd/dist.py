@@ -43,15 +43,19 @@ def gather_frame(local, nh: int, nw: int, shard_rows: int = DEFAULT_SHARD_ROWS, 
     assert tuple(local.shape) == (pr, nw, 3), (tuple(local.shape), (pr, nw, 3))
     if world == 1:
         return local[:nh]
+    # RCCL moves device tensors directly; a CPU backend (gloo, used by the tests and the one-GPU rehearsal) is fed
+    # through host staging copies.
+    staged = local.is_cuda and dist.get_backend(group) != "nccl"
+    send = local.cpu() if staged else local
     if rank == dst:
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.gather(local, gather_list=parts, dst=dst, group=group)
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, gather_list=parts, dst=dst, group=group)
         frame = out if out is not None else torch.empty((nh, nw, 3), dtype=local.dtype, device=local.device)
         for r, part in enumerate(parts):
             rows = torch.from_numpy(shard_row_index(nh, r, world, shard_rows)).to(local.device)
-            frame.index_copy_(0, rows, part[: rows.numel()])
+            frame.index_copy_(0, rows, part[: rows.numel()].to(local.device))
         return frame
-    dist.gather(local, gather_list=None, dst=dst, group=group)
+    dist.gather(send, gather_list=None, dst=dst, group=group)
     return None
 
 

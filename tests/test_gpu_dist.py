@@ -1,0 +1,67 @@
+"""The N > 1 bench path on a one-GPU box: two ranks (gloo, both on device 0) render their row shards with the HIP
+kernel, gather to rank 0, and the assembled frame equals the single-context frame bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    env = dict(os.environ, MRT_DIST_BACKEND="gloo", MRT_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "cornell_512_64spp_b8", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["samples_per_step"] == 512 * 512 * 64
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from micro_raytracer_amd import load_render, scenes
+    from micro_raytracer_amd.dist import ShardedSampler
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    render = load_render(scenes.cornell_box2(res=(160, 100), ssaa=1, sample=3))
+    ss = ShardedSampler(render, rank, world, 0, seed=6)
+    ss.execute(2)
+    ss.execute(1)
+    if rank == 0:
+        torch.cuda.synchronize()
+        np.save(out_path, ss.frame.cpu().numpy())
+        np.save(out_path + ".img.npy", ss.img())
+    dist.barrier()
+    ss.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_sampler_three_ranks_equal_single_context(tmp_path):
+    import torch.multiprocessing as mp
+    from micro_raytracer_amd import Sampler, load_render, scenes
+    out = str(tmp_path / "frame.npy")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 3, 29733, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    render = load_render(scenes.cornell_box2(res=(160, 100), ssaa=1, sample=3))
+    s = Sampler(seed=6)
+    s.execute(render, n_samples=3)
+    ref, _ = s.accum()
+    assert np.array_equal(np.load(out), ref)
+    assert np.array_equal(np.load(out + ".img.npy"), s.img())
