@@ -168,6 +168,8 @@ typedef struct mrt_stats {
     uint32_t lds_bytes;      /* LDS bytes per workgroup of the path-tracing kernel               */
     uint32_t block_threads;  /* workgroup size                                                   */
     uint32_t scene_bytes;    /* packed scene bytes staged per workgroup                          */
+    uint32_t k_split;        /* lanes per pixel of the last execute (sample chunks dealt round-robin) */
+    uint32_t reserved;
 } mrt_stats;
 
 /* Sampler::new + the first half of Sampler::execute's argument list (src/sampler.rs:19,28):

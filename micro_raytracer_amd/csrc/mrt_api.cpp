@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -13,6 +14,7 @@
 #include "../../include/mrt.h"
 #include "mrt_kernels.h"
 #include "mrt_pack.h"
+#include "mrt_trace.h"
 
 using namespace mrt;
 
@@ -42,6 +44,9 @@ void ok() { g_status = MRT_OK; }
 
 constexpr size_t kLdsLimit = 160u * 1024u;          // LDS per CU on gfx950
 constexpr size_t kTwoCopies = 78u * 1024u;          // <= this: two workgroups (two LDS copies) per CU
+constexpr size_t kSmallScene = 6u * 1024u;          // <= this: single-wave workgroups are allowed (24 LDS copies per CU)
+constexpr unsigned long long kSplitTargetWaves = 256ull * 24ull * 2ull;  // sample-split until two full rounds of 24 waves/CU
+constexpr unsigned long long kSmallGridWaves = 256ull * 24ull * 3ull;   // fewer 8x8 tiles than three full rounds of 24 waves/CU
 
 }  // namespace
 
@@ -54,6 +59,8 @@ struct mrt_ctx {
     u32 *d_blob = nullptr;
     float *d_accum = nullptr;            // [padded_rows][nw][3], rows past local_rows stay zero
     float *d_accum_own = nullptr;        // library-owned allocation (d_accum may point to caller memory)
+    float *d_partial = nullptr;          // chunk sums of a sample-split launch
+    size_t partial_floats = 0;
     u32 padded_rows = 0;
     unsigned long long *d_segments = nullptr;
     u32 count = 0;                       // Sampler.last_count
@@ -86,7 +93,7 @@ void free_ctx(mrt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->d_blob, c->d_accum_own, c->d_segments, c->d_full, c->d_ss, c->d_out, c->d_tmp, c->d_vl, c->d_vc, c->d_hl, c->d_hc, c->d_vw, c->d_hw};
+    void *ptrs[] = {c->d_blob, c->d_accum_own, c->d_partial, c->d_segments, c->d_full, c->d_ss, c->d_out, c->d_tmp, c->d_vl, c->d_vc, c->d_hl, c->d_hc, c->d_vw, c->d_hw};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -163,11 +170,17 @@ mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipMalloc((void **)&c->d_segments, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);
     if ((e = hipMemset(c->d_segments, 0, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
 
-    // launch shape: two 256-thread workgroups (2x2 wave tiles of 8x8 pixels) per CU while two LDS copies of the
-    // scene fit; beyond that one 512-thread workgroup (4x2 wave tiles) shares a single copy; scenes larger than
-    // the LDS are read through L2 instead.
+    // launch shape.  Scene <= 78 KB: 256-thread workgroups (2x2 wave tiles of 8x8 pixels, two LDS copies per CU fit), or
+    // single-wave workgroups when this context owns so few tiles that 4-wave workgroups could not balance 256 CUs
+    // (small frames, or one shard of an 8-GPU frame).  78-159 KB: one 512-thread workgroup (4x2 wave tiles) shares a
+    // single LDS copy per CU.  Larger scenes are read through L2 instead.
     c->scene_in_lds = blob_bytes + 1024 <= kLdsLimit;
-    if (blob_bytes <= kTwoCopies || !c->scene_in_lds) { c->block_threads = 256; c->pk.P.tiles_x = 2; c->pk.P.tiles_y = 2; }
+    const unsigned long long wave_tiles = (unsigned long long)((nw + 7) / 8) * ((c->local_rows + 7) / 8);
+    const char *force = getenv("MRT_BLOCK_THREADS");      // experiments only
+    u32 want = (wave_tiles < kSmallGridWaves && blob_bytes <= kSmallScene) ? 64u : 256u;
+    if (force) want = (u32)atoi(force);
+    if (!c->scene_in_lds || (blob_bytes <= kTwoCopies && want != 64u)) { c->block_threads = 256; c->pk.P.tiles_x = 2; c->pk.P.tiles_y = 2; }
+    else if (blob_bytes <= kTwoCopies) { c->block_threads = 64; c->pk.P.tiles_x = 1; c->pk.P.tiles_y = 1; }
     else { c->block_threads = 512; c->pk.P.tiles_x = 4; c->pk.P.tiles_y = 2; }
     if (c->scene_in_lds && (e = configure_pt(kLdsLimit)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipFuncSetAttribute", e);
 
@@ -177,7 +190,7 @@ mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
     c->P.blob = c->d_blob; c->P.accum = c->d_accum; c->P.segments = c->d_segments;
     c->P.count_segments = 1;
     memset(&c->stats, 0, sizeof c->stats);
-    c->stats.lds_bytes = c->scene_in_lds ? (u32)blob_bytes : 0;
+    c->stats.lds_bytes = (u32)pt_lds_bytes(c->pk.P, c->block_threads, c->scene_in_lds, c->pk.features);
     c->stats.block_threads = c->block_threads;
     c->stats.scene_bytes = (u32)blob_bytes;
     ok();
@@ -198,8 +211,29 @@ int mrt_execute(mrt_ctx *c, uint32_t n_samples, double *seconds)
         HIP_TRY(hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
         c->P.n_samples = n_samples;
         c->P.sample_base = c->count;
+        // sample split: spread a small frame over more wavefronts, one lane per (pixel, every k-th sample chunk)
+        const u32 g0 = c->count / kChunk;
+        const u32 n_chunks = (c->count + n_samples - 1u) / kChunk - g0 + 1u;
+        const unsigned long long wave_tiles = (unsigned long long)((c->pk.nw + 7) / 8) * ((c->local_rows + 7) / 8);
+        u32 k_split = 1;
+        while (k_split * 2u <= n_chunks && k_split < 16u && wave_tiles * k_split < kSplitTargetWaves) k_split *= 2u;
+        if (const char *f = getenv("MRT_K_SPLIT")) { k_split = (u32)atoi(f); if (k_split < 1u) k_split = 1u; while (k_split > n_chunks) k_split /= 2u; }
+        const size_t plane = (size_t)c->padded_rows * c->pk.nw * 3;
+        if (k_split > 1u) {
+            const size_t need = plane * n_chunks;
+            if (need > c->partial_floats) {
+                if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_floats = 0; }
+                if (hipMalloc((void **)&c->d_partial, need * sizeof(float)) != hipSuccess) k_split = 1u;    // fall back to one lane per pixel
+                else c->partial_floats = need;
+            }
+        }
+        c->P.k_split = k_split;
+        c->P.partial = c->d_partial;
+        c->P.partial_stride = plane;
+        c->stats.k_split = k_split;
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
+        if (k_split > 1u) HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_partial, (size_t)c->local_rows * c->pk.nw * 3, plane, n_chunks, c->stream));
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         float ms = 0;

@@ -75,19 +75,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         S.U = F;
 #endif
         S.P = &P;
-        float *px = P.accum + ((size_t)ry * P.nw + x) * 3u;
-        V3 acc = v3(px[0], px[1], px[2]);
+        LaneJob job;
+        job.k = blockIdx.z;
+        job.acc_px = P.accum + ((size_t)ry * P.nw + x) * 3u;
+        job.part_px = P.partial + ((size_t)ry * P.nw + x) * 3u;
+        job.part_stride = (size_t)P.partial_stride;
         if constexpr (lds_stash_for(FEAT)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
-            LdsStash st;
-            static_assert(BLOCK_THREADS == 256 || !lds_stash_for(FEAT), "the LDS stash is laid out for 256 threads");
+            LdsStash<BLOCK_THREADS> st;
             st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + ((P.blob_words + 3u) >> 2)) + threadIdx.x);
-            render_pixel<FEAT>(S, st, x, y, acc, segments);
+            render_pixel<FEAT>(S, st, x, y, job, segments);
         } else {
             RegStash st;
-            render_pixel<FEAT>(S, st, x, y, acc, segments);
+            render_pixel<FEAT>(S, st, x, y, job, segments);
         }
-        px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
     }
     if (P.count_segments) {
         // wave-level sum (every lane of the wavefront is here), one atomic per wavefront
@@ -95,6 +96,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if (lane == 0 && v) atomicAdd(P.segments, (unsigned long long)v);
     }
+}
+
+// acc[p] += chunk sums in chunk order (the canonical order of mrt_trace.h), one thread per accumulator word
+__global__ void __launch_bounds__(256) reduce_chunks(float *__restrict__ accum, const float *__restrict__ partial, size_t n_words,
+                                                     size_t stride, u32 n_chunks)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    float a = accum[i];
+    for (u32 j = 0; j < n_chunks; ++j) a += partial[(size_t)j * stride + i];
+    accum[i] = a;
 }
 
 __global__ void __launch_bounds__(256) tonemap_u8(const float *__restrict__ accum, unsigned char *__restrict__ out,
@@ -166,30 +178,42 @@ __global__ void math_selftest(int op, const float *a, const float *b, float *out
 }
 
 // ---- launchers (declared in mrt_kernels.h) ----
-// One instantiation per feature set for the common launch shape (scene in LDS, 256 threads); the 512-thread
-// shape (one LDS copy per CU, scenes of 78-160 KB) and the scene-in-L2 fallback carry every feature.
-template <u32 FEAT>
-static void launch_lds256(dim3 grid, size_t lds, hipStream_t stream, const Params &P)
+// One instantiation per feature set for the two common launch shapes with the scene in LDS: 256 threads (2x2 wave
+// tiles) and 64 threads (one 8x8 tile per workgroup, used when the frame has too few tiles to balance 256 CUs with
+// 4-wave workgroups).  The 512-thread shape (one LDS copy per CU, scenes of 78-160 KB) and the scene-in-L2 fallback
+// carry every feature.
+template <int THREADS, u32 FEAT>
+static void launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Params &P)
 {
-    hipLaunchKernelGGL((pt_megakernel<true, 256, FEAT>), grid, dim3(256), lds, stream, P, P.blob);
+    hipLaunchKernelGGL((pt_megakernel<true, THREADS, FEAT>), grid, dim3(THREADS), lds, stream, P, P.blob);
 }
 
 using LaunchFn = void (*)(dim3, size_t, hipStream_t, const Params &);
-static const LaunchFn kLds256[16] = {
-    launch_lds256<0>, launch_lds256<1>, launch_lds256<2>, launch_lds256<3>, launch_lds256<4>, launch_lds256<5>,
-    launch_lds256<6>, launch_lds256<7>, launch_lds256<8>, launch_lds256<9>, launch_lds256<10>, launch_lds256<11>,
-    launch_lds256<12>, launch_lds256<13>, launch_lds256<14>, launch_lds256<15>};
+#define MRT_ALL_FEATS(T) { launch_lds<T, 0>, launch_lds<T, 1>, launch_lds<T, 2>, launch_lds<T, 3>, launch_lds<T, 4>, launch_lds<T, 5>, \
+    launch_lds<T, 6>, launch_lds<T, 7>, launch_lds<T, 8>, launch_lds<T, 9>, launch_lds<T, 10>, launch_lds<T, 11>, \
+    launch_lds<T, 12>, launch_lds<T, 13>, launch_lds<T, 14>, launch_lds<T, 15> }
+static const LaunchFn kLds256[16] = MRT_ALL_FEATS(256);
+static const LaunchFn kLds64[16] = MRT_ALL_FEATS(64);
+
+size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 features)
+{
+    if (!scene_in_lds) return 0;
+    size_t lds = (size_t)P.blob_words * 4u;
+    if (block_threads != 512u && lds_stash_for(features & F_ALL)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
+    return lds;
+}
 
 hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 features, hipStream_t stream)
 {
-    if (block_threads != P.tiles_x * P.tiles_y * 64u || (block_threads != 256u && block_threads != 512u)) return hipErrorInvalidConfiguration;
+    if (block_threads != P.tiles_x * P.tiles_y * 64u) return hipErrorInvalidConfiguration;
     const u32 tile_w = P.tiles_x * 8u, tile_h = P.tiles_y * 8u;
-    dim3 grid((P.nw + tile_w - 1) / tile_w, (P.local_rows + tile_h - 1) / tile_h);
-    size_t lds = scene_in_lds ? (size_t)P.blob_words * 4u : 0;
+    dim3 grid((P.nw + tile_w - 1) / tile_w, (P.local_rows + tile_h - 1) / tile_h, P.k_split);
+    const size_t lds = pt_lds_bytes(P, block_threads, scene_in_lds, features);
     if (scene_in_lds) {
-        if (block_threads == 256u && lds_stash_for(features & F_ALL)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * 256u * sizeof(float);
         if (block_threads == 256u) kLds256[features & F_ALL](grid, lds, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<true, 512, F_ALL>), grid, dim3(512), lds, stream, P, P.blob);
+        else if (block_threads == 64u) kLds64[features & F_ALL](grid, lds, stream, P);
+        else if (block_threads == 512u) hipLaunchKernelGGL((pt_megakernel<true, 512, F_ALL>), grid, dim3(512), lds, stream, P, P.blob);
+        else return hipErrorInvalidConfiguration;
     } else {
         if (block_threads != 256u) return hipErrorInvalidConfiguration;
         hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL>), grid, dim3(256), 0, stream, P, P.blob);
@@ -197,21 +221,27 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     return hipGetLastError();
 }
 
-template <u32 FEAT>
+template <int THREADS, u32 FEAT>
 static hipError_t set_lds_attr(int bytes)
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 256, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, THREADS, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 hipError_t configure_pt(size_t max_lds_bytes)
 {
     const int b = (int)max_lds_bytes;
     hipError_t e;
-#define MRT_SET(F) if ((e = set_lds_attr<F>(b)) != hipSuccess) return e;
+#define MRT_SET(F) if ((e = set_lds_attr<256, F>(b)) != hipSuccess) return e; if ((e = set_lds_attr<64, F>(b)) != hipSuccess) return e;
     MRT_SET(0) MRT_SET(1) MRT_SET(2) MRT_SET(3) MRT_SET(4) MRT_SET(5) MRT_SET(6) MRT_SET(7)
     MRT_SET(8) MRT_SET(9) MRT_SET(10) MRT_SET(11) MRT_SET(12) MRT_SET(13) MRT_SET(14) MRT_SET(15)
 #undef MRT_SET
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 512, F_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
+}
+
+hipError_t launch_reduce_chunks(float *accum, const float *partial, size_t n_words, size_t stride, u32 n_chunks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reduce_chunks, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, accum, partial, n_words, stride, n_chunks);
+    return hipGetLastError();
 }
 
 hipError_t launch_tonemap(const float *accum, unsigned char *out, u32 n_px, float rc, float gamma, float wexp, hipStream_t stream)

@@ -75,6 +75,7 @@ struct Params {
     u32 nw, nh;
     u32 local_rows, shard_index, shard_count, shard_rows;
     u32 n_samples, sample_base;
+    u32 k_split;             // lanes per pixel (each owns every k_split-th sample chunk of the launch)
     u32 seed_lo, seed_hi;
     u32 bounce;
     float q;                 // 1 - min(loss, 1), src/rt.rs:571
@@ -95,6 +96,8 @@ struct Params {
     // device pointers
     const u32 *blob;
     float *accum;            // [local_rows][nw][3]
+    float *partial;          // [chunks of this launch][padded_rows][nw][3], used when k_split > 1
+    unsigned long long partial_stride;   // floats per chunk plane
     unsigned long long *segments;
 };
 

@@ -550,29 +550,53 @@ struct RegStash {
 };
 #if defined(__HIPCC__) || defined(__HIP__)
 typedef __attribute__((address_space(3))) volatile float lds_vfloat;   // keeps ds_read / ds_write addressing
+template <u32 THREADS>
 struct LdsStash {
-    lds_vfloat *base;         // &lds_stash[tid]
-    MRT_HD void put(u32 slot, float x) { base[slot * 256u] = x; }      // 256-thread workgroups only
-    MRT_HD float get(u32 slot) const { return base[slot * 256u]; }
+    lds_vfloat *base;         // &lds_stash[tid]; slot-major columns of THREADS floats
+    MRT_HD void put(u32 slot, float x) { base[slot * THREADS] = x; }
+    MRT_HD float get(u32 slot) const { return base[slot * THREADS]; }
 };
 #endif
 template <class St> MRT_HD void st_put3(St &st, u32 slot, V3 v) { st.put(slot, v.x); st.put(slot + 1, v.y); st.put(slot + 2, v.z); }
 template <class St> MRT_HD V3 st_get3(const St &st, u32 slot) { return v3(st.get(slot), st.get(slot + 1), st.get(slot + 2)); }
 
+// Samples are accumulated in a canonical order that does not depend on how the work is split: the global sample
+// indices are cut into aligned chunks of kChunk; a chunk is summed from 0 in index order, and chunk sums are added to
+// the pixel's accumulator in chunk order.  A lane owns every k_split-th chunk of a launch (k_split = 1: all of them,
+// added straight to the accumulator; k_split > 1: chunk sums go to `partial` and reduce_chunks adds them in order),
+// so small frames can be spread over more wavefronts with bit-identical results.
+constexpr u32 kChunk = 16;
+
+struct LaneJob {
+    u32 k;                 // this lane's chunk phase, 0 <= k < P.k_split
+    float *acc_px;         // &accum[pixel][0]      (read / written when k_split == 1)
+    float *part_px;        // &partial[0][pixel][0] (written when k_split > 1)
+    size_t part_stride;    // floats between consecutive chunks of one pixel in `partial`
+};
+
 // All samples of one supersampled pixel: Sampler::execute's per-pixel body, n_samples times
 // (src/sampler.rs:45-70 calling RayTracer::iter / reduce_light, src/rt.rs:937-994, whose iterator
-// is RaytraceIterator::next, src/rt.rs:1014-1066).  acc is the running colors[(x, y)] entry.
+// is RaytraceIterator::next, src/rt.rs:1014-1066).
 template <u32 FEAT, class Stash>
-MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, V3 &acc_io, u32 &segments)
+MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &job, u32 &segments)
 {
     const Params &P = *S.P;
     const u32 pixel = y * P.nw + x;
     const u32 pix_key = mix32(pixel + P.seed_lo) ^ P.seed_hi;      // path_key = mix32(pix_key + sample * kGold)
     const V3 sky_init = v3(P.sky_init[0], P.sky_init[1], P.sky_init[2]);
-    st_put3(st, ST_ACC, acc_io);
+    const u32 s_base = P.sample_base, s_stop = P.sample_base + P.n_samples;
+    const u32 g0 = s_base / kChunk;
+    const u32 n_chunks = (s_stop - 1u) / kChunk - g0 + 1u;          // n_samples > 0
+    const bool direct = P.k_split == 1u;
+    if (direct) st_put3(st, ST_ACC, v3(job.acc_px[0], job.acc_px[1], job.acc_px[2]));
     st_put3(st, ST_FOCUS, pixel_focus(P, (float)x, (float)y));
 
-    u32 s = 0;
+    u32 j = job.k;                                                  // local chunk index of this lane
+    u32 s = (g0 + j) * kChunk;                                      // global sample index
+    if (s < s_base) s = s_base;
+    u32 s_end = (g0 + j + 1u) * kChunk;
+    if (s_end > s_stop) s_end = s_stop;
+    V3 csum = v3(0.0f, 0.0f, 0.0f);
     u32 fresh = 1;
     u32 pk = 0, b = 0;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
@@ -587,9 +611,9 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, V3 &acc_io, u32 
     for (;;) {
         MRT_PROBE(PH_ITER);
         if (fresh) {
-            if (s >= P.n_samples) break;
+            if (j >= n_chunks) break;
             MRT_PROBE(PH_REGEN);
-            pk = mix32(pix_key + (P.sample_base + s) * kGold);
+            pk = mix32(pix_key + s * kGold);
             camera_ray(P, st_get3(st, ST_FOCUS), pk, o, d);
             T = v3(1.0f, 1.0f, 1.0f); L = v3(0.0f, 0.0f, 0.0f);
             pwr = 1.0f; b = 0;
@@ -697,13 +721,29 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, V3 &acc_io, u32 
             }
         }
         if (ended) {
-            st_put3(st, ST_ACC, add(st_get3(st, ST_ACC), contrib));
+            csum = add(csum, contrib);
             ++s;
             fresh = 1;
+            if (s == s_end) {                                       // chunk complete: flush its sum
+                if (direct) {
+                    st_put3(st, ST_ACC, add(st_get3(st, ST_ACC), csum));
+                } else {
+                    float *q = job.part_px + (size_t)j * job.part_stride;
+                    q[0] = csum.x; q[1] = csum.y; q[2] = csum.z;
+                }
+                csum = v3(0.0f, 0.0f, 0.0f);
+                j += P.k_split;
+                s = (g0 + j) * kChunk;
+                s_end = s + kChunk;
+                if (s_end > s_stop) s_end = s_stop;
+            }
         }
         fresh = opaque(fresh);
     }
-    acc_io = st_get3(st, ST_ACC);
+    if (direct) {
+        const V3 acc = st_get3(st, ST_ACC);
+        job.acc_px[0] = acc.x; job.acc_px[1] = acc.y; job.acc_px[2] = acc.z;
+    }
     segments = seg;
 }
 

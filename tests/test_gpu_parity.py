@@ -99,18 +99,42 @@ def test_scene_parity(name, oracle_mod):
 
 
 def test_incremental_execute_equals_batched():
-    """execute(1) x 4 == execute(4): the result is a pure function of (scene, seed, sample index)."""
-    from micro_raytracer_amd import scenes
-    render, _ = make_holder(scenes.cornell_box(res=(64, 48), sample=4))
-    a = _gpu_render(render, 4)
-    from micro_raytracer_amd import Sampler
+    """The accumulator is a pure function of (scene, seed, set of sample indices): batches aligned to the 16-sample
+    accumulation chunks give identical bits however they are cut; unaligned cuts only re-associate f32 additions."""
+    from micro_raytracer_amd import Sampler, scenes
+    render, _ = make_holder(scenes.cornell_box(res=(64, 48), sample=48))
+    a = _gpu_render(render, 48)
     b = Sampler(seed=5)
-    for _ in range(4):
-        b.execute(render)
+    for n in (16, 32):
+        b.execute(render, n_samples=n)
+    c = Sampler(seed=5)
+    for n in (1, 3, 12, 20, 12):
+        c.execute(render, n_samples=n)
     ra, ca = a.accum()
     rb, cb = b.accum()
-    assert ca == cb == 4
+    rc, cc = c.accum()
+    assert ca == cb == cc == 48
     assert np.array_equal(ra, rb)
+    assert np.abs(ra - rc).max() / 48 <= 1e-6
+
+
+def test_sample_split_launch_is_bit_identical(monkeypatch):
+    """Spreading a small frame over k lanes per pixel (chunk sums reduced in chunk order) changes no bit."""
+    from micro_raytracer_amd import scenes
+    render, _ = make_holder(scenes.cornell_box2(res=(96, 64), ssaa=1, sample=64))
+    monkeypatch.setenv("MRT_K_SPLIT", "1")
+    s1 = _gpu_render(render, 64)
+    r1, _ = s1.accum()
+    assert s1.stats()["k_split"] == 1
+    for k in ("2", "4"):
+        monkeypatch.setenv("MRT_K_SPLIT", k)
+        sk = _gpu_render(render, 64)
+        assert sk.stats()["k_split"] == int(k)
+        assert np.array_equal(sk.accum()[0], r1)
+    monkeypatch.delenv("MRT_K_SPLIT")
+    sa = _gpu_render(render, 64)            # the automatic choice splits this small frame
+    assert sa.stats()["k_split"] > 1
+    assert np.array_equal(sa.accum()[0], r1)
 
 
 def test_shards_reassemble_to_whole_frame():
