@@ -42,7 +42,7 @@ def build_render(spec, spp):
     return load_render(getattr(scenes, kind)(sample=spp, **spec))
 
 
-def cpu_baseline(render, seconds_target=15.0):
+def cpu_baseline(render, seconds_target=12.0):
     """The CPU oracle (a C restatement of the reference's algorithm, kind "port": the Rust reference
     cannot be built here) timed on this host's cores on a bounded sample of the same workload."""
     from micro_raytracer_amd import _abi
@@ -178,6 +178,12 @@ def main():
                      "Gsegments_per_s": total_segments / elapsed / 1e9},
             "kernel": {"block_threads": st["block_threads"], "lds_bytes": st["lds_bytes"], "scene_bytes": st["scene_bytes"]},
         }
+        # Sampler::img on the accumulated frame (outside the timed region): tone map (+ Lanczos3 when ssaa != 1)
+        img = ss.img()
+        ist = ss.s.stats()
+        img_bytes = 15.0 * nw * nh + (0 if (nw, nh) == tuple(render.frame.res) else 3.0 * nw * nh + 2 * 12.0 * nw * render.frame.res[1] + 3.0 * render.frame.res[0] * render.frame.res[1])
+        line["img"] = {"kernels_ms": ist["img_ms"], "algorithmic_bytes": img_bytes, "GBps": img_bytes / (ist["img_ms"] * 1e-3) / 1e9 if ist["img_ms"] > 0 else None,
+                       "out": [int(img.shape[1]), int(img.shape[0])]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(render)
         print(json.dumps(line), flush=True)

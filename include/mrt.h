@@ -170,6 +170,7 @@ typedef struct mrt_stats {
     uint32_t scene_bytes;    /* packed scene bytes staged per workgroup                          */
     uint32_t k_split;        /* lanes per pixel of the last execute (sample chunks dealt round-robin) */
     uint32_t reserved;
+    double   img_ms;         /* HIP-event time of the kernels of the last mrt_img / mrt_img_ss (tone map + resize) */
 } mrt_stats;
 
 /* Sampler::new + the first half of Sampler::execute's argument list (src/sampler.rs:19,28):

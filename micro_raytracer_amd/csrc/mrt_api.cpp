@@ -412,6 +412,7 @@ static int img_tonemap(mrt_ctx *c)
     if (count == 0) return fail(MRT_ERR_STATE, "mrt_img: no samples accumulated (the reference would panic on an empty map, src/sampler.rs:85)");
     const float rc = 1.0f / (float)count;
     const float wexp = (1.0f - c->pk.exp) * (1.0f - c->pk.exp);
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(launch_tonemap(src, c->d_ss, c->pk.nw * c->pk.nh, rc, c->pk.gamma, wexp, c->stream));
     return MRT_OK;
 }
@@ -423,7 +424,9 @@ int mrt_img_ss(mrt_ctx *c, uint8_t *rgb8)
     if (rc) return rc;
     if ((rc = img_prepare(c))) return rc;
     if ((rc = img_tonemap(c))) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1)); c->stats.img_ms = ms; }
     HIP_TRY(hipMemcpy(rgb8, c->d_ss, (size_t)c->pk.nw * c->pk.nh * 3, hipMemcpyDeviceToHost));
     ok();
     return MRT_OK;
@@ -438,14 +441,18 @@ int mrt_img(mrt_ctx *c, uint8_t *rgb8)
     if ((rc = img_tonemap(c))) return rc;
     const u32 nw = c->pk.nw, nh = c->pk.nh, rw = c->pk.res_w, rh = c->pk.res_h;
     if (rw == nw && rh == nh) {    // image 0.24 resize copies when the dimensions match
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1)); c->stats.img_ms = ms; }
         HIP_TRY(hipMemcpy(rgb8, c->d_ss, (size_t)nw * nh * 3, hipMemcpyDeviceToHost));
         ok();
         return MRT_OK;
     }
     HIP_TRY(launch_lanczos_v(c->d_ss, c->d_tmp, nw, rh, c->d_vl, c->d_vc, c->d_vw, c->vcap, c->stream));
     HIP_TRY(launch_lanczos_h(c->d_tmp, c->d_out, nw, rw, rh, c->d_hl, c->d_hc, c->d_hw, c->hcap, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1)); c->stats.img_ms = ms; }
     HIP_TRY(hipMemcpy(rgb8, c->d_out, (size_t)rw * rh * 3, hipMemcpyDeviceToHost));
     ok();
     return MRT_OK;

@@ -90,6 +90,8 @@ class ShardedSampler:
     def img(self):
         if self.rank != 0:
             return None
+        if self.world == 1:
+            return self.s.img()              # the context already holds every row
         import torch
         torch.cuda.synchronize(self.dev)
         self.s.set_accum_device(self.frame.data_ptr(), self.count)
