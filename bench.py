@@ -53,9 +53,10 @@ def cpu_baseline(render, seconds_target=12.0):
     nh, nw = o.nh, o.nw
     rows = (nh // 2 - 32, nh // 2 + 32)     # 64 rows through the middle of the frame
     band = (rows[1] - rows[0]) * nw
-    t = o.execute(1, threads=cores, rows=rows)         # calibration pass (also warms the thread pool)
-    t = min(t, o.execute(1, threads=cores, rows=rows))
-    spp2 = max(1, min(4096, int(seconds_target * band / t / band)))
+    o.execute(1, threads=cores, rows=rows)             # warm-up (thread creation, page faults)
+    cal = 8
+    t = o.execute(cal, threads=cores, rows=rows)       # calibration
+    spp2 = max(1, min(4096, int(seconds_target * cal / t)))
     t2 = o.execute(spp2, threads=cores, rows=rows)
     n = band * spp2
     o.close()
