@@ -77,9 +77,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         S.P = &P;
         LaneJob job;
         job.k = blockIdx.z;
-        job.acc_px = P.accum + ((size_t)ry * P.nw + x) * 3u;
-        job.part_px = P.partial + ((size_t)ry * P.nw + x) * 3u;
-        job.part_stride = (size_t)P.partial_stride;
+        job.word = (ry * P.nw + x) * 3u;        // < 2^32: mrt_create limits a shard to 2^30 pixels
         if constexpr (lds_stash_for(FEAT)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
             LdsStash<BLOCK_THREADS> st;

@@ -214,7 +214,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     out.nw = to_usize_u32(P.w);
     out.nh = to_usize_u32(P.h);
     if (out.nw == 0 || out.nh == 0) { err = "empty frame (res * ssaa truncates to 0)"; return MRT_ERR_SCENE; }
-    if ((unsigned long long)out.nw * out.nh > 0xffffffffull) { err = "frame has more than 2^32 supersampled pixels"; return MRT_ERR_LIMIT; }
+    if ((unsigned long long)out.nw * out.nh > (1ull << 30)) { err = "frame has more than 2^30 supersampled pixels"; return MRT_ERR_LIMIT; }
     P.nw = out.nw; P.nh = out.nh;
     P.aspect = P.w / P.h;
     const float tan_fov = tanf((0.5f * fr.cam.fov) * (kPi / 180.0f));    // f32::to_radians().tan(), src/rt.rs:902

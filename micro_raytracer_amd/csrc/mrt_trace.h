@@ -542,7 +542,7 @@ MRT_HD bool coin(float p, u32 pk, u32 dim)
 // camera focus point).  RegStash keeps it in registers; LdsStash parks it in a per-lane LDS column (slot-major, so
 // lane i always hits bank i) to free VGPRs for the traversal loop without the compiler spilling to scratch,
 // whose write-backs would show up as HBM traffic.  volatile: the values must really live in LDS across the loop.
-enum : u32 { ST_ACC = 0, ST_FOCUS = 3, ST_SLOTS = 6 };
+enum : u32 { ST_ACC = 0, ST_FOCUS = 3, ST_PIXKEY = 6, ST_CHUNK = 7, ST_SEND = 8, ST_WORD = 9, ST_SLOTS = 10 };
 struct RegStash {
     float v[ST_SLOTS];
     MRT_HD void put(u32 slot, float x) { v[slot] = x; }
@@ -569,9 +569,8 @@ constexpr u32 kChunk = 16;
 
 struct LaneJob {
     u32 k;                 // this lane's chunk phase, 0 <= k < P.k_split
-    float *acc_px;         // &accum[pixel][0]      (read / written when k_split == 1)
-    float *part_px;        // &partial[0][pixel][0] (written when k_split > 1)
-    size_t part_stride;    // floats between consecutive chunks of one pixel in `partial`
+    u32 word;              // 3 * (shard-local pixel index): accum[word..word+2] is this pixel (k_split == 1, read and
+                           // written in place); partial[chunk * partial_stride + word ..] receives chunk sums otherwise
 };
 
 // All samples of one supersampled pixel: Sampler::execute's per-pixel body, n_samples times
@@ -588,14 +587,21 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     const u32 g0 = s_base / kChunk;
     const u32 n_chunks = (s_stop - 1u) / kChunk - g0 + 1u;          // n_samples > 0
     const bool direct = P.k_split == 1u;
-    if (direct) st_put3(st, ST_ACC, v3(job.acc_px[0], job.acc_px[1], job.acc_px[2]));
+    if (direct) st_put3(st, ST_ACC, v3(P.accum[job.word], P.accum[job.word + 1u], P.accum[job.word + 2u]));
     st_put3(st, ST_FOCUS, pixel_focus(P, (float)x, (float)y));
 
-    u32 j = job.k;                                                  // local chunk index of this lane
-    u32 s = (g0 + j) * kChunk;                                      // global sample index
+    // chunk bookkeeping and the pixel's hash key are only needed when a path starts or a chunk ends: stashed too
+    st.put(ST_PIXKEY, u2f(pix_key));
+    st.put(ST_WORD, u2f(job.word));
+    st.put(ST_CHUNK, u2f(job.k));                                   // local chunk index of this lane
+    u32 s = (g0 + job.k) * kChunk;                                  // global sample index
     if (s < s_base) s = s_base;
-    u32 s_end = (g0 + j + 1u) * kChunk;
-    if (s_end > s_stop) s_end = s_stop;
+    {
+        u32 e = (g0 + job.k + 1u) * kChunk;
+        if (e > s_stop) e = s_stop;
+        st.put(ST_SEND, u2f(e));
+    }
+    bool more = job.k < n_chunks;
     V3 csum = v3(0.0f, 0.0f, 0.0f);
     u32 fresh = 1;
     u32 pk = 0, b = 0;
@@ -611,9 +617,9 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     for (;;) {
         MRT_PROBE(PH_ITER);
         if (fresh) {
-            if (j >= n_chunks) break;
+            if (!more) break;
             MRT_PROBE(PH_REGEN);
-            pk = mix32(pix_key + s * kGold);
+            pk = mix32(f2u(st.get(ST_PIXKEY)) + s * kGold);
             camera_ray(P, st_get3(st, ST_FOCUS), pk, o, d);
             T = v3(1.0f, 1.0f, 1.0f); L = v3(0.0f, 0.0f, 0.0f);
             pwr = 1.0f; b = 0;
@@ -724,25 +730,30 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
             csum = add(csum, contrib);
             ++s;
             fresh = 1;
-            if (s == s_end) {                                       // chunk complete: flush its sum
+            if (s == f2u(st.get(ST_SEND))) {                        // chunk complete: flush its sum
+                u32 j = f2u(st.get(ST_CHUNK));
                 if (direct) {
                     st_put3(st, ST_ACC, add(st_get3(st, ST_ACC), csum));
                 } else {
-                    float *q = job.part_px + (size_t)j * job.part_stride;
+                    float *q = P.partial + ((size_t)j * P.partial_stride + f2u(st.get(ST_WORD)));
                     q[0] = csum.x; q[1] = csum.y; q[2] = csum.z;
                 }
                 csum = v3(0.0f, 0.0f, 0.0f);
                 j += P.k_split;
+                more = j < n_chunks;
                 s = (g0 + j) * kChunk;
-                s_end = s + kChunk;
-                if (s_end > s_stop) s_end = s_stop;
+                u32 e = s + kChunk;
+                if (e > s_stop) e = s_stop;
+                st.put(ST_CHUNK, u2f(j));
+                st.put(ST_SEND, u2f(e));
             }
         }
         fresh = opaque(fresh);
     }
     if (direct) {
         const V3 acc = st_get3(st, ST_ACC);
-        job.acc_px[0] = acc.x; job.acc_px[1] = acc.y; job.acc_px[2] = acc.z;
+        float *q = P.accum + f2u(st.get(ST_WORD));
+        q[0] = acc.x; q[1] = acc.y; q[2] = acc.z;
     }
     segments = seg;
 }

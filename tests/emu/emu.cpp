@@ -45,7 +45,7 @@ int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, ui
     Params P = pk.P;
     P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
     P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32);
-    P.n_samples = n_samples; P.sample_base = sample_base; P.k_split = 1;
+    P.n_samples = n_samples; P.sample_base = sample_base; P.k_split = 1; P.accum = accum;
     if (row1 > pk.nh) row1 = pk.nh;
     Scn S;
     S.F = reinterpret_cast<const float *>(pk.blob.data());
@@ -61,9 +61,8 @@ int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, ui
             const uint32_t y = next.fetch_add(1);
             if (y >= row1) break;
             for (uint32_t x = 0; x < pk.nw; ++x) {
-                float *px = accum + ((size_t)y * pk.nw + x) * 3;
                 u32 sg = 0;
-                { RegStash st; LaneJob job; job.k = 0; job.acc_px = px; job.part_px = nullptr; job.part_stride = 0; render_pixel<F_ALL>(S, st, x, y, job, sg); }
+                { RegStash st; LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u; render_pixel<F_ALL>(S, st, x, y, job, sg); }
                 local += sg;
             }
         }

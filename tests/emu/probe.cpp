@@ -23,6 +23,7 @@ extern "C" int probe_divergence(const mrt_render_desc *d, uint64_t seed, uint32_
     Params P = pk.P;
     P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
     P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.n_samples = n_samples; P.sample_base = 0; P.k_split = 1;
+    std::vector<float> frame((size_t)pk.nw * pk.nh * 3, 0.0f); P.accum = frame.data();
     Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.P = &P;
     for (u32 p = 0; p < PH_COUNT; ++p) { active[p] = 0; executed[p] = 0; }
     for (uint32_t ty = tile_y0; ty < tile_y0 + tiles_y; ++ty)
@@ -33,8 +34,8 @@ extern "C" int probe_divergence(const mrt_render_desc *d, uint64_t seed, uint32_
                 const uint32_t x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
                 if (x >= pk.nw || y >= pk.nh) continue;
                 g_rec = &rec[l];
-                float px[3] = {0, 0, 0}; u32 sg = 0; RegStash st;
-                LaneJob job; job.k = 0; job.acc_px = px; job.part_px = nullptr; job.part_stride = 0;
+                u32 sg = 0; RegStash st;
+                LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u;
                 render_pixel<F_ALL>(S, st, x, y, job, sg);
                 g_rec = nullptr;
                 if (rec[l].size() > max_it) max_it = rec[l].size();
