@@ -43,7 +43,9 @@ void ok() { g_status = MRT_OK; }
     } while (0)
 
 constexpr size_t kLdsLimit = 160u * 1024u;          // LDS per CU on gfx950
-constexpr size_t kTwoCopies = 78u * 1024u;          // <= this: two workgroups (two LDS copies) per CU
+constexpr size_t kTwoCopies = 68u * 1024u;          // <= this: two 256-thread workgroups (two LDS copies + their stash) fit a CU
+constexpr size_t kStash256 = 10u * 1024u + 256u;     // lane stash of a 256-thread workgroup (ST_SLOTS * 256 * 4 B, rounded up)
+constexpr size_t kOneCopyStash = 118u * 1024u;      // <= this: one 1024-thread workgroup with its 40 KB stash fits a CU
 constexpr size_t kSmallScene = 6u * 1024u;          // <= this: single-wave workgroups are allowed (24 LDS copies per CU)
 constexpr unsigned long long kSplitTargetWaves = 256ull * 24ull * 2ull;  // sample-split until two full rounds of 24 waves/CU
 constexpr unsigned long long kSmallGridWaves = 256ull * 24ull * 3ull;   // fewer 8x8 tiles than three full rounds of 24 waves/CU
@@ -170,18 +172,34 @@ mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipMalloc((void **)&c->d_segments, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);
     if ((e = hipMemset(c->d_segments, 0, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
 
-    // launch shape.  Scene <= 78 KB: 256-thread workgroups (2x2 wave tiles of 8x8 pixels, two LDS copies per CU fit), or
-    // single-wave workgroups when this context owns so few tiles that 4-wave workgroups could not balance 256 CUs
-    // (small frames, or one shard of an 8-GPU frame).  78-159 KB: one 512-thread workgroup (4x2 wave tiles) shares a
-    // single LDS copy per CU.  Larger scenes are read through L2 instead.
+    // launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
+    // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most.
+    //   256 threads (2x2 wave tiles of 8x8 pixels) + 10 KB lane stash per copy of the scene;
+    //   64 threads instead when this context owns few tiles (small frames, one shard of a multi-GPU frame);
+    //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves;
+    //   scenes that do not fit the LDS are read through L2.
     c->scene_in_lds = blob_bytes + 1024 <= kLdsLimit;
     const unsigned long long wave_tiles = (unsigned long long)((nw + 7) / 8) * ((c->local_rows + 7) / 8);
     const char *force = getenv("MRT_BLOCK_THREADS");      // experiments only
-    u32 want = (wave_tiles < kSmallGridWaves && blob_bytes <= kSmallScene) ? 64u : 256u;
-    if (force) want = (u32)atoi(force);
-    if (!c->scene_in_lds || (blob_bytes <= kTwoCopies && want != 64u)) { c->block_threads = 256; c->pk.P.tiles_x = 2; c->pk.P.tiles_y = 2; }
-    else if (blob_bytes <= kTwoCopies) { c->block_threads = 64; c->pk.P.tiles_x = 1; c->pk.P.tiles_y = 1; }
-    else { c->block_threads = 512; c->pk.P.tiles_x = 4; c->pk.P.tiles_y = 2; }
+    u32 want = 256u;
+    if (c->scene_in_lds) {
+        const size_t w256 = 4u * (kLdsLimit / (blob_bytes + kStash256));
+        const size_t w512 = 8u * (kLdsLimit / (blob_bytes ? blob_bytes : 1));
+        const size_t w1024 = blob_bytes <= kOneCopyStash ? 16u : 0u;
+        if (w256 >= 16u) want = (wave_tiles < kSmallGridWaves && blob_bytes <= kSmallScene) ? 64u : 256u;
+        else if (w512 >= 16u) want = 512u;
+        else if (w1024 >= 16u) want = 1024u;
+        else want = (w256 >= w512 && blob_bytes <= kTwoCopies) ? 256u : 512u;
+    }
+    if (force && c->scene_in_lds) {
+        const u32 f = (u32)atoi(force);
+        if ((f == 64u || f == 256u) && blob_bytes <= kTwoCopies) want = f;
+        if (f == 1024u && blob_bytes <= kOneCopyStash) want = f;
+        if (f == 512u) want = f;
+    }
+    c->block_threads = want;
+    c->pk.P.tiles_x = want == 64u ? 1u : (want == 256u ? 2u : 4u);
+    c->pk.P.tiles_y = want == 64u ? 1u : (want == 1024u ? 4u : 2u);
     if (c->scene_in_lds && (e = configure_pt(kLdsLimit)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipFuncSetAttribute", e);
 
     c->P = c->pk.P;

@@ -24,12 +24,14 @@ namespace mrt {
 // VALU-issue bound, so the light variants (planes / spheres / boxes, no maps, no lights, no triangles) are squeezed to
 // 6 waves per SIMD (80 VGPRs, a few spills: measured +14 % on the Cornell box); the heavier variants lose more to
 // spills than they gain from occupancy and keep the compiler's choice.  MRT_WAVES_PER_EU overrides (experiments).
-constexpr bool lds_stash_for(u32 feat)
+// The per-path LDS stash (mrt_trace.h) is used by every launch shape that has room for it next to the scene: the
+// 64- and 256-thread workgroups with the scene in LDS.  It moves 7-25 VGPRs of rarely touched state out of the loop.
+constexpr bool lds_stash_for(bool scene_in_lds, int block_threads)
 {
 #ifdef MRT_NO_STASH
     return false;
 #else
-    return (feat & ~F_BOX) == 0;
+    return scene_in_lds && block_threads != 512;
 #endif
 }
 constexpr int waves_for(u32 feat)
@@ -37,7 +39,7 @@ constexpr int waves_for(u32 feat)
 #ifdef MRT_WAVES_PER_EU
     return MRT_WAVES_PER_EU;
 #else
-    return feat == 0 ? 6 : (feat == F_BOX ? 5 : 2);
+    return (feat & (F_LIGHTS | F_TRI)) == 0 ? 6 : 4;
 #endif
 }
 
@@ -78,7 +80,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         LaneJob job;
         job.k = blockIdx.z;
         job.word = (ry * P.nw + x) * 3u;        // < 2^32: mrt_create limits a shard to 2^30 pixels
-        if constexpr (lds_stash_for(FEAT)) {
+        if constexpr (lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
             LdsStash<BLOCK_THREADS> st;
             st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + ((P.blob_words + 3u) >> 2)) + threadIdx.x);
@@ -179,7 +181,7 @@ __global__ void math_selftest(int op, const float *a, const float *b, float *out
 // One instantiation per feature set for the two common launch shapes with the scene in LDS: 256 threads (2x2 wave
 // tiles) and 64 threads (one 8x8 tile per workgroup, used when the frame has too few tiles to balance 256 CUs with
 // 4-wave workgroups).  The 512-thread shape (one LDS copy per CU, scenes of 78-160 KB) and the scene-in-L2 fallback
-// carry every feature.
+// and the 1024-thread shape (one LDS copy + stash per CU, 16 waves) carry every feature.
 template <int THREADS, u32 FEAT>
 static void launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Params &P)
 {
@@ -197,7 +199,7 @@ size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 f
 {
     if (!scene_in_lds) return 0;
     size_t lds = (size_t)P.blob_words * 4u;
-    if (block_threads != 512u && lds_stash_for(features & F_ALL)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
+    if (lds_stash_for(scene_in_lds, (int)block_threads)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
     return lds;
 }
 
@@ -211,6 +213,7 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
         if (block_threads == 256u) kLds256[features & F_ALL](grid, lds, stream, P);
         else if (block_threads == 64u) kLds64[features & F_ALL](grid, lds, stream, P);
         else if (block_threads == 512u) hipLaunchKernelGGL((pt_megakernel<true, 512, F_ALL>), grid, dim3(512), lds, stream, P, P.blob);
+        else if (block_threads == 1024u) hipLaunchKernelGGL((pt_megakernel<true, 1024, F_ALL>), grid, dim3(1024), lds, stream, P, P.blob);
         else return hipErrorInvalidConfiguration;
     } else {
         if (block_threads != 256u) return hipErrorInvalidConfiguration;
@@ -233,6 +236,7 @@ hipError_t configure_pt(size_t max_lds_bytes)
     MRT_SET(0) MRT_SET(1) MRT_SET(2) MRT_SET(3) MRT_SET(4) MRT_SET(5) MRT_SET(6) MRT_SET(7)
     MRT_SET(8) MRT_SET(9) MRT_SET(10) MRT_SET(11) MRT_SET(12) MRT_SET(13) MRT_SET(14) MRT_SET(15)
 #undef MRT_SET
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 1024, F_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 512, F_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
 }
 
