@@ -147,7 +147,8 @@ typedef struct mrt_opts {
     uint32_t shard_rows;    /* 0 => default (8) */
     /* In-process multi-GPU (the single-process reference binary): n_devices > 1 makes one
      * sub-context per device 0..n_devices-1, row-sharded as above, gathered on device 0 by one
-     * RCCL ncclGather per mrt_execute.  Mutually exclusive with shard_count > 1. */
+     * RCCL ncclGather per mrt_execute (librccl.so is loaded on demand).  Mutually exclusive with
+     * shard_count > 1.  n_devices == 0 takes the count from the environment variable MRT_GPUS. */
     uint32_t n_devices;
     uint32_t flags;         /* MRT_FLAG_* */
     uint32_t reserved[4];

@@ -2,7 +2,9 @@
 // Replaces the reference's Sampler (src/sampler.rs:11-100); there is no CPU rendering path here:
 // without a HIP device every entry point that needs one fails with MRT_ERR_DEVICE.
 #include <hip/hip_runtime_api.h>
+#include <dlfcn.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,6 +43,34 @@ void ok() { g_status = MRT_OK; }
         hipError_t e_ = (expr);                                                                                \
         if (e_ != hipSuccess) return fail(MRT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));    \
     } while (0)
+
+// ---- RCCL, loaded on demand (only in-process multi-device contexts need it; signatures from rccl/rccl.h) ----
+typedef struct ncclComm *ncclComm_t;
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;                                        // rccl.h:236
+    int (*CommDestroy)(ncclComm_t) = nullptr;                                                              // rccl.h:260
+    int (*Gather)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;             // rccl.h:745
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;                                                          // rccl.h:339
+    bool load(std::string &err)
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        Gather = (decltype(Gather))dlsym(lib, "ncclGather");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !Gather || !GroupStart || !GroupEnd || !GetErrorString) { err = "librccl.so lacks a required symbol"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclFloat = 7;                        // ncclFloat32, rccl.h:466
 
 constexpr size_t kLdsLimit = 160u * 1024u;          // LDS per CU on gfx950
 constexpr size_t kTwoCopies = 68u * 1024u;          // <= this: two 256-thread workgroups (two LDS copies + their stash) fit a CU
@@ -81,6 +111,11 @@ struct mrt_ctx {
     float *d_vw = nullptr, *d_hw = nullptr;
     u32 vcap = 0, hcap = 0;
     mrt_stats stats;
+    // in-process multi-device context (mrt_opts.n_devices > 1): one sharded sub-context per device, gathered on device 0
+    std::vector<mrt_ctx *> subs;
+    std::vector<ncclComm_t> comms;
+    float *d_gather = nullptr;           // [n_devices][padded_rows][nw][3] on device 0
+    u32 *d_rowmap = nullptr;             // [n_devices][padded_rows] frame row of each gathered row (0xffffffff: padding)
 };
 
 namespace {
@@ -94,7 +129,11 @@ int set_device(const mrt_ctx *c)
 void free_ctx(mrt_ctx *c)
 {
     if (!c) return;
+    for (mrt_ctx *sub : c->subs) free_ctx(sub);
+    for (ncclComm_t cm : c->comms) if (cm) g_rccl.CommDestroy(cm);
     (void)hipSetDevice(c->device);
+    if (c->d_gather) (void)hipFree(c->d_gather);
+    if (c->d_rowmap) (void)hipFree(c->d_rowmap);
     void *ptrs[] = {c->d_blob, c->d_accum_own, c->d_partial, c->d_segments, c->d_full, c->d_ss, c->d_out, c->d_tmp, c->d_vl, c->d_vc, c->d_hl, c->d_hc, c->d_vw, c->d_hw};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -118,12 +157,8 @@ int mrt_device_count(void)
     return n;
 }
 
-mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
+static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
 {
-    g_err.clear();
-    if (!desc || !opts) { fail(MRT_ERR_ARG, "mrt_create: null argument"); return nullptr; }
-    if (opts->abi_version != MRT_ABI_VERSION) { fail(MRT_ERR_ARG, "mrt_create: ABI version %u, library has %u", opts->abi_version, MRT_ABI_VERSION); return nullptr; }
-    if (opts->n_devices > 1) { fail(MRT_ERR_ARG, "mrt_create: in-process multi-device contexts are not available in this build; use one context per device with shard_index/shard_count"); return nullptr; }
     const u32 shard_count = opts->shard_count ? opts->shard_count : 1;
     if (opts->shard_index >= shard_count) { fail(MRT_ERR_ARG, "mrt_create: shard_index %u >= shard_count %u", opts->shard_index, shard_count); return nullptr; }
 
@@ -215,44 +250,113 @@ mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
     return c;
 }
 
+// In-process multi-device context: n sharded sub-contexts (device r renders row blocks b = r mod n), one RCCL
+// ncclGather of the padded shard accumulators to device 0 per mrt_execute, rows placed into the frame by scatter_rows.
+static mrt_ctx *create_group(const mrt_render_desc *desc, const mrt_opts *opts, u32 n)
+{
+    std::string err;
+    if (!g_rccl.load(err)) { fail(MRT_ERR_DEVICE, "mrt_create: %s", err.c_str()); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || (u32)ndev < n) { fail(MRT_ERR_DEVICE, "mrt_create: n_devices = %u but %d HIP device(s) are visible", n, ndev); return nullptr; }
+    mrt_ctx *g = new mrt_ctx();
+    const int rc = pack_scene(desc, g->pk, err);
+    if (rc != MRT_OK) { fail(rc, "mrt_create: %s", err.c_str()); delete g; return nullptr; }
+    g->device = 0; g->seed = opts->seed;
+    g->shard_count = 1; g->shard_index = 0; g->shard_rows = opts->shard_rows ? opts->shard_rows : 8;
+    g->local_rows = g->pk.nh; g->padded_rows = g->pk.nh;
+    for (u32 y = 0; y < g->pk.nh; ++y) g->row_of.push_back(y);
+    for (u32 r = 0; r < n; ++r) {
+        mrt_opts o = *opts;
+        o.n_devices = 0; o.device = (int)r; o.shard_index = r; o.shard_count = n; o.shard_rows = g->shard_rows;
+        mrt_ctx *sub = create_single(desc, &o);
+        if (!sub) { free_ctx(g); return nullptr; }
+        g->subs.push_back(sub);
+    }
+    auto bail = [&](const char *what, const char *why) { fail(MRT_ERR_DEVICE, "mrt_create: %s: %s", what, why); free_ctx(g); return (mrt_ctx *)nullptr; };
+    hipError_t e;
+    if ((e = hipSetDevice(0)) != hipSuccess) return bail("hipSetDevice", hipGetErrorString(e));
+    if ((e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", hipGetErrorString(e));
+    if ((e = hipEventCreate(&g->ev0)) != hipSuccess || (e = hipEventCreate(&g->ev1)) != hipSuccess) return bail("hipEventCreate", hipGetErrorString(e));
+    const u32 pr = g->subs[0]->padded_rows, nw = g->pk.nw, nh = g->pk.nh;
+    const size_t plane = (size_t)pr * nw * 3;
+    if ((e = hipMalloc((void **)&g->d_full, (size_t)nh * nw * 3 * sizeof(float))) != hipSuccess) return bail("hipMalloc(frame)", hipGetErrorString(e));
+    if ((e = hipMemset(g->d_full, 0, (size_t)nh * nw * 3 * sizeof(float))) != hipSuccess) return bail("hipMemset", hipGetErrorString(e));
+    if ((e = hipMalloc((void **)&g->d_gather, plane * n * sizeof(float))) != hipSuccess) return bail("hipMalloc(gather)", hipGetErrorString(e));
+    std::vector<u32> rowmap((size_t)n * pr, 0xffffffffu);
+    for (u32 r = 0; r < n; ++r) for (u32 i = 0; i < g->subs[r]->local_rows; ++i) rowmap[(size_t)r * pr + i] = g->subs[r]->row_of[i];
+    if ((e = hipMalloc((void **)&g->d_rowmap, rowmap.size() * sizeof(u32))) != hipSuccess) return bail("hipMalloc(rowmap)", hipGetErrorString(e));
+    if ((e = hipMemcpy(g->d_rowmap, rowmap.data(), rowmap.size() * sizeof(u32), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(rowmap)", hipGetErrorString(e));
+    std::vector<int> devs(n);
+    for (u32 r = 0; r < n; ++r) devs[r] = (int)r;
+    g->comms.assign(n, nullptr);
+    const int nrc = g_rccl.CommInitAll(g->comms.data(), (int)n, devs.data());
+    if (nrc != 0) return bail("ncclCommInitAll", g_rccl.GetErrorString(nrc));
+    g->P = g->pk.P;
+    memset(&g->stats, 0, sizeof g->stats);
+    g->stats.block_threads = g->subs[0]->block_threads; g->stats.lds_bytes = g->subs[0]->stats.lds_bytes; g->stats.scene_bytes = g->subs[0]->stats.scene_bytes;
+    ok();
+    return g;
+}
+
+mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
+{
+    g_err.clear();
+    if (!desc || !opts) { fail(MRT_ERR_ARG, "mrt_create: null argument"); return nullptr; }
+    if (opts->abi_version != MRT_ABI_VERSION) { fail(MRT_ERR_ARG, "mrt_create: ABI version %u, library has %u", opts->abi_version, MRT_ABI_VERSION); return nullptr; }
+    u32 n = opts->n_devices;
+    if (n == 0) if (const char *e = getenv("MRT_GPUS")) n = (u32)atoi(e);       // the Rust shim's knob
+    const bool force_group = getenv("MRT_FORCE_RCCL") != nullptr;               // tests: the group path on one device
+    if (n > 1 || (n == 1 && force_group)) {
+        if (opts->shard_count > 1) { fail(MRT_ERR_ARG, "mrt_create: n_devices and shard_count are mutually exclusive"); return nullptr; }
+        return create_group(desc, opts, n);
+    }
+    return create_single(desc, opts);
+}
+
 void mrt_destroy(mrt_ctx *ctx) { free_ctx(ctx); }
 
-int mrt_execute(mrt_ctx *c, uint32_t n_samples, double *seconds)
+// asynchronous half of mrt_execute on one device: everything up to the closing event
+static int exec_launch(mrt_ctx *c, uint32_t n_samples)
 {
-    if (!c) return fail(MRT_ERR_ARG, "mrt_execute: null context");
-    if ((unsigned long long)c->count + n_samples > 0xffffffffull) return fail(MRT_ERR_LIMIT, "mrt_execute: sample count overflows u32");
-    const auto t0 = std::chrono::steady_clock::now();
     int rc = set_device(c);
     if (rc) return rc;
     c->stats.kernel_ms = 0; c->stats.gather_ms = 0; c->stats.launches = 0; c->stats.samples = 0; c->stats.segments = 0;
-    if (n_samples && c->local_rows) {
-        HIP_TRY(hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
-        c->P.n_samples = n_samples;
-        c->P.sample_base = c->count;
-        // sample split: spread a small frame over more wavefronts, one lane per (pixel, every k-th sample chunk)
-        const u32 g0 = c->count / kChunk;
-        const u32 n_chunks = (c->count + n_samples - 1u) / kChunk - g0 + 1u;
-        const unsigned long long wave_tiles = (unsigned long long)((c->pk.nw + 7) / 8) * ((c->local_rows + 7) / 8);
-        u32 k_split = 1;
-        while (k_split * 2u <= n_chunks && k_split < 16u && wave_tiles * k_split < kSplitTargetWaves) k_split *= 2u;
-        if (const char *f = getenv("MRT_K_SPLIT")) { k_split = (u32)atoi(f); if (k_split < 1u) k_split = 1u; while (k_split > n_chunks) k_split /= 2u; }
-        const size_t plane = (size_t)c->padded_rows * c->pk.nw * 3;
-        if (k_split > 1u) {
-            const size_t need = plane * n_chunks;
-            if (need > c->partial_floats) {
-                if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_floats = 0; }
-                if (hipMalloc((void **)&c->d_partial, need * sizeof(float)) != hipSuccess) k_split = 1u;    // fall back to one lane per pixel
-                else c->partial_floats = need;
-            }
+    if (!(n_samples && c->local_rows)) return MRT_OK;
+    HIP_TRY(hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
+    c->P.n_samples = n_samples;
+    c->P.sample_base = c->count;
+    // sample split: spread a small frame over more wavefronts, one lane per (pixel, every k-th sample chunk)
+    const u32 g0 = c->count / kChunk;
+    const u32 n_chunks = (c->count + n_samples - 1u) / kChunk - g0 + 1u;
+    const unsigned long long wave_tiles = (unsigned long long)((c->pk.nw + 7) / 8) * ((c->local_rows + 7) / 8);
+    u32 k_split = 1;
+    while (k_split * 2u <= n_chunks && k_split < 16u && wave_tiles * k_split < kSplitTargetWaves) k_split *= 2u;
+    if (const char *f = getenv("MRT_K_SPLIT")) { k_split = (u32)atoi(f); if (k_split < 1u) k_split = 1u; while (k_split > n_chunks) k_split /= 2u; }
+    const size_t plane = (size_t)c->padded_rows * c->pk.nw * 3;
+    if (k_split > 1u) {
+        const size_t need = plane * n_chunks;
+        if (need > c->partial_floats) {
+            if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_floats = 0; }
+            if (hipMalloc((void **)&c->d_partial, need * sizeof(float)) != hipSuccess) k_split = 1u;    // fall back to one lane per pixel
+            else c->partial_floats = need;
         }
-        c->P.k_split = k_split;
-        c->P.partial = c->d_partial;
-        c->P.partial_stride = plane;
-        c->stats.k_split = k_split;
-        HIP_TRY(hipEventRecord(c->ev0, c->stream));
-        HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
-        if (k_split > 1u) HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_partial, (size_t)c->local_rows * c->pk.nw * 3, plane, n_chunks, c->stream));
-        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    }
+    c->P.k_split = k_split;
+    c->P.partial = c->d_partial;
+    c->P.partial_stride = plane;
+    c->stats.k_split = k_split;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
+    if (k_split > 1u) HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_partial, (size_t)c->local_rows * c->pk.nw * 3, plane, n_chunks, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    return MRT_OK;
+}
+
+static int exec_finish(mrt_ctx *c, uint32_t n_samples)
+{
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (n_samples && c->local_rows) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -262,6 +366,52 @@ int mrt_execute(mrt_ctx *c, uint32_t n_samples, double *seconds)
         c->stats.samples = (uint64_t)c->local_rows * c->pk.nw * n_samples;
     }
     c->count += n_samples;                                        // src/sampler.rs:76
+    return MRT_OK;
+}
+
+static int exec_group(mrt_ctx *g, uint32_t n_samples)
+{
+    const u32 n = (u32)g->subs.size();
+    int rc;
+    for (mrt_ctx *s : g->subs) if ((rc = exec_launch(s, n_samples))) return rc;
+    // one gather per batch: rank r sends its padded shard accumulator, device 0 receives rank i at offset i * plane
+    const auto tg = std::chrono::steady_clock::now();
+    const size_t plane = (size_t)g->subs[0]->padded_rows * g->pk.nw * 3;
+    int nrc = g_rccl.GroupStart();
+    for (u32 r = 0; r < n && nrc == 0; ++r) {
+        HIP_TRY(hipSetDevice((int)r));
+        nrc = g_rccl.Gather(g->subs[r]->d_accum, r == 0 ? g->d_gather : nullptr, plane, kNcclFloat, 0, g->comms[r], g->subs[r]->stream);
+    }
+    const int nrc2 = g_rccl.GroupEnd();
+    if (nrc != 0 || nrc2 != 0) return fail(MRT_ERR_DEVICE, "ncclGather: %s", g_rccl.GetErrorString(nrc ? nrc : nrc2));
+    for (mrt_ctx *s : g->subs) if ((rc = exec_finish(s, n_samples))) return rc;    // syncs every stream (kernel + gather)
+    HIP_TRY(hipSetDevice(0));
+    HIP_TRY(launch_scatter_rows(g->d_full, g->d_gather, g->d_rowmap, n * g->subs[0]->padded_rows, g->pk.nw * 3u, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->count += n_samples;
+    g->full_count = g->count;
+    memset(&g->stats, 0, offsetof(mrt_stats, lds_bytes));
+    for (mrt_ctx *s : g->subs) {
+        if (s->stats.kernel_ms > g->stats.kernel_ms) g->stats.kernel_ms = s->stats.kernel_ms;
+        g->stats.samples += s->stats.samples; g->stats.segments += s->stats.segments; g->stats.launches += s->stats.launches;
+    }
+    g->stats.k_split = g->subs[0]->stats.k_split;
+    g->stats.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg).count();
+    return MRT_OK;
+}
+
+int mrt_execute(mrt_ctx *c, uint32_t n_samples, double *seconds)
+{
+    if (!c) return fail(MRT_ERR_ARG, "mrt_execute: null context");
+    if ((unsigned long long)c->count + n_samples > 0xffffffffull) return fail(MRT_ERR_LIMIT, "mrt_execute: sample count overflows u32");
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    if (!c->subs.empty()) {
+        if ((rc = exec_group(c, n_samples))) return rc;
+    } else {
+        if ((rc = exec_launch(c, n_samples))) return rc;
+        if ((rc = exec_finish(c, n_samples))) return rc;
+    }
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ok();
     return MRT_OK;
@@ -282,6 +432,12 @@ int mrt_accum_local(mrt_ctx *c, float *rgb, uint32_t *rows)
     if (!c) return fail(MRT_ERR_ARG, "mrt_accum_local: null context");
     int rc = set_device(c);
     if (rc) return rc;
+    if (!c->subs.empty()) {       // a multi-device context owns every row
+        if (rows) memcpy(rows, c->row_of.data(), sizeof(u32) * c->local_rows);
+        if (rgb) HIP_TRY(hipMemcpy(rgb, c->d_full, (size_t)c->pk.nh * c->pk.nw * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        ok();
+        return MRT_OK;
+    }
     if (rows) memcpy(rows, c->row_of.data(), sizeof(u32) * c->local_rows);
     if (rgb && c->local_rows) HIP_TRY(hipMemcpy(rgb, c->d_accum, (size_t)c->local_rows * c->pk.nw * 3 * sizeof(float), hipMemcpyDeviceToHost));
     ok();
@@ -313,7 +469,7 @@ int mrt_accum(mrt_ctx *c, float *rgb, uint32_t *count)
 int mrt_accum_device_ptr(mrt_ctx *c, void **dev_ptr, size_t *bytes)
 {
     if (!c) return fail(MRT_ERR_ARG, "mrt_accum_device_ptr: null context");
-    if (dev_ptr) *dev_ptr = c->d_accum;
+    if (dev_ptr) *dev_ptr = c->subs.empty() ? c->d_accum : c->d_full;
     if (bytes) *bytes = (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float);
     ok();
     return MRT_OK;
@@ -330,6 +486,7 @@ int mrt_padded_rows(const mrt_ctx *c, uint32_t *rows)
 int mrt_bind_accum(mrt_ctx *c, void *dev_ptr, size_t bytes)
 {
     if (!c) return fail(MRT_ERR_ARG, "mrt_bind_accum: null context");
+    if (!c->subs.empty()) return fail(MRT_ERR_STATE, "mrt_bind_accum: not available on a multi-device context");
     int rc = set_device(c);
     if (rc) return rc;
     const size_t need = (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float);
@@ -350,6 +507,7 @@ int mrt_set_accum_device(mrt_ctx *c, const void *dev_rgb, uint32_t count)
     int rc = set_device(c);
     if (rc) return rc;
     const size_t bytes = (size_t)c->pk.nw * c->pk.nh * 3 * sizeof(float);
+    if (!c->subs.empty()) return fail(MRT_ERR_STATE, "mrt_set_accum_device: use mrt_set_accum on a multi-device context");
     if (c->shard_count == 1) {
         HIP_TRY(hipMemcpy(c->d_accum, dev_rgb, bytes, hipMemcpyDeviceToDevice));
         c->count = count;
@@ -368,7 +526,16 @@ int mrt_set_accum(mrt_ctx *c, const float *rgb, uint32_t count)
     int rc = set_device(c);
     if (rc) return rc;
     const size_t row_bytes = (size_t)c->pk.nw * 3 * sizeof(float);
-    if (c->shard_count == 1) {
+    if (!c->subs.empty()) {
+        HIP_TRY(hipMemcpy(c->d_full, rgb, row_bytes * c->pk.nh, hipMemcpyHostToDevice));
+        for (mrt_ctx *s : c->subs) {
+            HIP_TRY(hipSetDevice(s->device));
+            for (u32 i = 0; i < s->local_rows; ++i)
+                HIP_TRY(hipMemcpy((char *)s->d_accum + row_bytes * i, (const char *)rgb + row_bytes * s->row_of[i], row_bytes, hipMemcpyHostToDevice));
+            s->count = count;
+        }
+        c->count = count; c->full_count = count;
+    } else if (c->shard_count == 1) {
         HIP_TRY(hipMemcpy(c->d_accum, rgb, row_bytes * c->pk.nh, hipMemcpyHostToDevice));
         c->count = count;
     } else {
@@ -386,6 +553,14 @@ int mrt_reset(mrt_ctx *c)
     if (!c) return fail(MRT_ERR_ARG, "mrt_reset: null context");
     int rc = set_device(c);
     if (rc) return rc;
+    if (!c->subs.empty()) {
+        for (mrt_ctx *s : c->subs) if ((rc = mrt_reset(s))) return rc;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemset(c->d_full, 0, (size_t)c->pk.nh * c->pk.nw * 3 * sizeof(float)));
+        c->count = 0; c->full_count = 0;
+        ok();
+        return MRT_OK;
+    }
     HIP_TRY(hipMemset(c->d_accum, 0, (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float)));
     if (c->d_full) { (void)hipFree(c->d_full); c->d_full = nullptr; }
     c->count = 0; c->full_count = 0;

@@ -10,6 +10,7 @@ hipError_t configure_pt(size_t max_lds_bytes);
 size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 features);
 hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 features, hipStream_t stream);
 hipError_t launch_reduce_chunks(float *accum, const float *partial, size_t n_words, size_t stride, u32 n_chunks, hipStream_t stream);
+hipError_t launch_scatter_rows(float *frame, const float *gathered, const u32 *rowmap, u32 n_rows, u32 row_words, hipStream_t stream);
 hipError_t launch_tonemap(const float *accum, unsigned char *out, u32 n_px, float rc, float gamma, float wexp, hipStream_t stream);
 hipError_t launch_lanczos_v(const unsigned char *src, float *dst, u32 sw, u32 dh, const u32 *left, const u32 *count,
                             const float *weight, u32 cap, hipStream_t stream);

@@ -109,6 +109,18 @@ __global__ void __launch_bounds__(256) reduce_chunks(float *__restrict__ accum, 
     accum[i] = a;
 }
 
+// rows of the gathered shard accumulators -> their place in the frame (multi-device contexts)
+__global__ void __launch_bounds__(256) scatter_rows(float *__restrict__ frame, const float *__restrict__ gathered, const u32 *__restrict__ rowmap,
+                                                    u32 n_rows, u32 row_words)
+{
+    const u32 r = blockIdx.y;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows || i >= row_words) return;
+    const u32 y = rowmap[r];
+    if (y == 0xffffffffu) return;
+    frame[(size_t)y * row_words + i] = gathered[(size_t)r * row_words + i];
+}
+
 __global__ void __launch_bounds__(256) tonemap_u8(const float *__restrict__ accum, unsigned char *__restrict__ out,
                                                   u32 n_px, float rc, float gamma, float wexp)
 {
@@ -243,6 +255,12 @@ hipError_t configure_pt(size_t max_lds_bytes)
 hipError_t launch_reduce_chunks(float *accum, const float *partial, size_t n_words, size_t stride, u32 n_chunks, hipStream_t stream)
 {
     hipLaunchKernelGGL(reduce_chunks, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, accum, partial, n_words, stride, n_chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_rows(float *frame, const float *gathered, const u32 *rowmap, u32 n_rows, u32 row_words, hipStream_t stream)
+{
+    hipLaunchKernelGGL(scatter_rows, dim3((row_words + 255) / 256, n_rows), dim3(256), 0, stream, frame, gathered, rowmap, n_rows, row_words);
     return hipGetLastError();
 }
 

@@ -21,10 +21,11 @@ from .scene import Render
 
 class Sampler:
     def __init__(self, workers: int = 24, n_dim: int = 64, *, seed: int = 1, device: int = -1,
-                 shard_index: int = 0, shard_count: int = 1, shard_rows: int = 8):
+                 shard_index: int = 0, shard_count: int = 1, shard_rows: int = 8, n_devices: int = 0):
         self.workers, self.n_dim = workers, n_dim
         self.seed, self.device = seed, device
         self.shard_index, self.shard_count, self.shard_rows = shard_index, shard_count, shard_rows
+        self.n_devices = n_devices      # > 1: one process drives that many GPUs (RCCL gather inside mrt_execute)
         self._ctx = None
         self._holder = None
         self._key = None
@@ -44,6 +45,7 @@ class Sampler:
         opts.seed = self.seed
         opts.device = self.device
         opts.shard_index, opts.shard_count, opts.shard_rows = self.shard_index, self.shard_count, self.shard_rows
+        opts.n_devices = self.n_devices
         ctx = L.mrt_create(C.cast(self._holder.ptr(), C.c_void_p), C.byref(opts))
         if not ctx:
             raise _lib.MrtError(L.mrt_last_status(), L.mrt_last_error().decode())
