@@ -1,0 +1,71 @@
+"""Edge-case render descriptions shared by the CPU (x86 kernel headers) and GPU parity tests."""
+import numpy as np
+
+
+def _base(res=(24, 16), ssaa=1, sample=2, bounce=3, **cam):
+    c = {"pos": [0, -1.5, 0.2], "fov": 60, "gamma": 0.7, "exp": 0.5}
+    c.update(cam)
+    return {"rt": {"sample": sample, "bounce": bounce, "loss": 0.15}, "frame": {"res": list(res), "ssaa": ssaa, "cam": c},
+            "scene": {"renderer": [], "sky": {"color": [0.2, 0.3, 0.5], "pwr": 0.6}}}
+
+
+def cases():
+    out = {}
+    d = _base()
+    d["scene"].pop("renderer")
+    out["empty_scene_sky_only"] = d                                        # primary miss everywhere: raw sky colour
+
+    d = _base(bounce=0)
+    d["scene"]["renderer"] = [{"type": "sphere", "r": 0.5, "mat": {"albedo": "#80ff40"}}]
+    d["scene"]["light"] = [{"type": "point", "pos": [-1, -2, 1]}]
+    out["bounce_zero"] = d                                                 # exactly one hit per path
+
+    d = _base(bounce=40, sample=1, res=(16, 10))
+    d["scene"]["renderer"] = [{"type": "box", "sizes": [4, 4, 4], "mat": {"rough": 0.2}},                # camera inside a closed box
+                              {"type": "sphere", "r": 0.3, "pos": [0, 0.5, 0], "mat": {"metal": 1}}]
+    out["deep_bounces_inside_box"] = d
+
+    d = _base(res=(1, 1), sample=5)
+    d["scene"]["renderer"] = [{"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.5]}]
+    out["one_pixel"] = d
+
+    d = _base(res=(40, 30), ssaa=0.5, sample=2)                            # ssaa < 1: 20x15 supersampled, Lanczos upscale
+    d["scene"]["renderer"] = [{"type": "sphere", "r": 0.6}, {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.6], "mat": {"rough": 1}}]
+    d["scene"]["light"] = [{"type": "dir", "dir": [0.2, 1, -1], "pwr": 0.8, "color": "#fff0e0"}]
+    out["ssaa_below_one_upscale"] = d
+
+    d = _base(res=(30, 20), ssaa=1.3, sample=2)                            # fractional ssaa: 39 x 26 (truncated) frame
+    d["scene"]["renderer"] = [{"type": "triangle", "vtx": [[0.7, 0.2, -0.4], [0.0, 0.3, 0.7], [-0.7, 0.1, -0.4]], "mat": {"albedo": "#ff8040", "rough": 0.4}},
+                              {"type": "triangle", "vtx": [[0.7, 0.6, -0.4], [-0.7, 0.6, -0.4], [0.0, 0.6, 0.7]], "mat": {"emit": 0.5}}]
+    out["lone_triangles_two_sided"] = d
+
+    d = _base(sample=3)
+    d["scene"]["renderer"] = [{"type": "sphere", "r": 0.4, "mat": {"opacity": 0.0, "glass": 1.5}},      # strong refraction incl. total internal reflection
+                              {"type": "sphere", "r": 0.2, "pos": [0, 0, 0], "mat": {"emit": 1, "albedo": "#ffd080"}},   # light inside the glass ball
+                              {"type": "plane", "n": [0, 1, 0.2], "pos": [0, 1.5, 0], "dir": [0.3, 0, -1, 0.4], "mat": {"rough": 1}}]   # rotated plane
+    out["glass_around_emitter_rotated_plane"] = d
+
+    d = _base(sample=2)
+    lights = [{"type": "point", "pos": [np.cos(a) * 2, -1 + np.sin(a), 1.0], "pwr": 0.1, "color": [1, 0.5 + 0.5 * np.cos(a), 0.7]} for a in np.linspace(0, 6, 9)]
+    d["scene"]["renderer"] = [{"type": "box", "sizes": [0.6, 0.6, 0.6], "dir": [0.1, 0.4, -1, 0.2], "mat": {"rough": 0.5}},
+                              {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.3], "mat": {"rough": 1}}]
+    d["scene"]["light"] = lights
+    out["nine_lights"] = d
+
+    d = _base(sample=2, aprt=0.0)                                          # pinhole: the centre row has dir.z == -0 before the transform
+    d["frame"]["cam"]["pos"] = [0, -1.5, 0.0]
+    d["scene"]["renderer"] = [{"type": "plane", "n": [0, 0, 1], "pos": [0, 0, 0.0], "mat": {"rough": 1}},          # edge-on plane through the camera
+                              {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.5], "mat": {"albedo": "#4080ff"}},
+                              {"type": "box", "sizes": [0.5, 0.5, 0.5], "pos": [0, 0.5, 0]}]
+    out["pinhole_signed_zero_rays"] = d
+
+    d = _base(sample=2)
+    d["scene"]["renderer"] = [{"type": "mesh", "mesh": [[[0.5, 0.2, -0.3], [0.0, 0.3, 0.6], [-0.5, 0.1, -0.3]]], "mat": {"rough": 0.3}},   # 1-triangle mesh (octree of one leaf)
+                              {"type": "sphere", "r": 0.25, "inst": []}]                                                                     # renderer without instances
+    out["tiny_mesh_and_instanceless_renderer"] = d
+
+    d = _base(sample=2)
+    d["scene"]["renderer"] = [{"type": "sphere", "r": 0.5, "mat": {"albedo": [1.7, 0.2, -0.3], "opacity": -2.0, "rough": 2.5, "metal": 0.5, "loss": 0}}]   # out-of-gamut but legal values
+    d["rt"]["loss"] = 3.0                                                   # loss.min(1.0) -> every bounce has pwr 0
+    out["out_of_range_but_legal_material"] = d
+    return out
