@@ -228,6 +228,10 @@ int mrt_img(mrt_ctx *ctx, uint8_t *rgb8);
 /* The tone-mapped supersampled image before the resize: rgb8[nh][nw][3] (src/sampler.rs:84-96). */
 int mrt_img_ss(mrt_ctx *ctx, uint8_t *rgb8);
 
+/* `img.save(&filename)` of the reference's CLI (src/cli.rs:168,174) for the lossless formats it is used with:
+ * ".ppm" (P6) and ".png" (8-bit RGB, stored deflate).  Host-only helper; returns MRT_ERR_ARG for other extensions. */
+int mrt_save_image(const char *path, const uint8_t *rgb8, uint32_t w, uint32_t h);
+
 /* Zero the accumulators and last_count (a fresh Sampler on the same scene). */
 int mrt_reset(mrt_ctx *ctx);
 

@@ -14,7 +14,7 @@ SYMBOLS = (
     "mrt_create", "mrt_destroy", "mrt_execute", "mrt_dims", "mrt_accum", "mrt_accum_local", "mrt_accum_device_ptr",
     "mrt_set_accum", "mrt_img", "mrt_img_ss", "mrt_reset", "mrt_get_stats", "mrt_last_error", "mrt_last_status",
     "mrt_abi_version", "mrt_device_count", "mrt_selftest_math", "mrt_padded_rows", "mrt_bind_accum",
-    "mrt_set_accum_device",
+    "mrt_set_accum_device", "mrt_save_image",
 )
 
 
@@ -67,6 +67,7 @@ def lib():
     L.mrt_padded_rows.argtypes = [vp, u32p]
     L.mrt_bind_accum.argtypes = [vp, vp, C.c_size_t]
     L.mrt_set_accum_device.argtypes = [vp, vp, u32]
+    L.mrt_save_image.argtypes = [C.c_char_p, u8p, u32, u32]
     L.mrt_selftest_math.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p, C.c_size_t]
     _LIB = L
     return L
@@ -89,3 +90,10 @@ def selftest_math(op, a, b=None, device=0):
     check(lib().mrt_selftest_math(device, op, a.ctypes.data_as(C.POINTER(C.c_float)), bp,
                                   out.ctypes.data_as(C.POINTER(C.c_float)), a.size))
     return out
+
+
+def save_image(path, rgb8):
+    """img.save(filename) (src/cli.rs:168,174) for .ppm / .png."""
+    import numpy as np
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    check(lib().mrt_save_image(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0]))

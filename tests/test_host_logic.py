@@ -198,3 +198,18 @@ def test_tonemap_known_answers(oracle_mod):
         assert abs(int(got) - want) <= 1
     # `as u8` saturates and maps NaN to 0; powf of a negative base is NaN
     assert oracle_mod.tonemap_px([np.nan, -1.0, 0.0], 1, 0.8, 0.2).tolist() == [0, 0, 0]
+
+
+def test_image_writers_roundtrip(tmp_path):
+    """mrt_save_image: the .ppm / .png files `img.save` would write (src/cli.rs:168,174) decode back to the same bytes."""
+    from PIL import Image
+    from micro_raytracer_amd import _lib
+    rng = np.random.default_rng(5)
+    for shape in ((7, 13, 3), (300, 257, 3)):                      # second one spans several 64 KB stored-deflate blocks
+        img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        for ext in ("png", "ppm"):
+            p = tmp_path / f"o{shape[0]}.{ext}"
+            _lib.save_image(p, img)
+            assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), img)
+    with pytest.raises(_lib.MrtError):
+        _lib.save_image(tmp_path / "o.jpg", img)
