@@ -57,7 +57,7 @@ struct Rccl {
     bool load(std::string &err)
     {
         if (lib) return true;
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        for (const char *name : {"/opt/rocm/lib/librccl.so", "librccl.so", "librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
         if (!lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
         CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");

@@ -67,29 +67,42 @@ def test_sharded_sampler_three_ranks_equal_single_context(tmp_path):
     assert np.array_equal(np.load(out + ".img.npy"), s.img())
 
 
-def test_in_process_group_context_rccl_gather_on_one_device(monkeypatch):
+_GROUP_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["MRT_ROOT"])
+from micro_raytracer_amd import Sampler, load_render, scenes
+render = load_render(scenes.cornell_box2(res=(120, 72), ssaa=1, sample=20))
+plain = Sampler(seed=3)
+plain.execute(render, n_samples=16)
+plain.execute(render, n_samples=4)
+ref, cnt = plain.accum()
+os.environ["MRT_FORCE_RCCL"] = "1"
+g = Sampler(seed=3, n_devices=1)
+g.execute(render, n_samples=16)
+st = g.stats()
+assert st["samples"] == 120 * 72 * 16 and st["segments"] > 0
+g.execute(render, n_samples=4)
+got, gcnt = g.accum()
+assert gcnt == cnt == 20
+assert np.array_equal(got, ref)
+assert np.array_equal(g.img(), plain.img())
+loc, rows = g.accum_local()
+assert np.array_equal(loc, ref) and list(rows) == list(range(72))
+g.reset()
+g.set_accum(ref, cnt)                     # resume: push a frame back into the shards, keep sampling
+g.execute(render, n_samples=12)
+plain.execute(render, n_samples=12)
+assert np.array_equal(g.accum()[0], plain.accum()[0])
+print("GROUP-OK")
+"""
+
+
+def test_in_process_group_context_rccl_gather_on_one_device():
     """mrt_opts.n_devices: the single-process multi-GPU path (sub-contexts + one ncclGather + row scatter), exercised
-    with a communicator of one device; frame, image and a resumed render equal the plain context bit for bit."""
-    from micro_raytracer_amd import Sampler, load_render, scenes
-    render = load_render(scenes.cornell_box2(res=(120, 72), ssaa=1, sample=20))
-    plain = Sampler(seed=3)
-    plain.execute(render, n_samples=16)
-    plain.execute(render, n_samples=4)
-    ref, cnt = plain.accum()
-    monkeypatch.setenv("MRT_FORCE_RCCL", "1")
-    g = Sampler(seed=3, n_devices=1)
-    g.execute(render, n_samples=16)
-    st = g.stats()
-    assert st["samples"] == 120 * 72 * 16 and st["segments"] > 0
-    g.execute(render, n_samples=4)
-    got, gcnt = g.accum()
-    assert gcnt == cnt == 20
-    assert np.array_equal(got, ref)
-    assert np.array_equal(g.img(), plain.img())
-    loc, rows = g.accum_local()
-    assert np.array_equal(loc, ref) and list(rows) == list(range(72))
-    g.reset()
-    g.set_accum(ref, cnt)                     # resume: push a frame back into the shards, keep sampling
-    g.execute(render, n_samples=12)
-    plain.execute(render, n_samples=12)
-    assert np.array_equal(g.accum()[0], plain.accum()[0])
+    with a communicator of one device; frame, image and a resumed render equal the plain context bit for bit.
+    Runs in a fresh interpreter without torch, like the reference's binary: librccl.so is loaded by the library itself
+    (a process that already holds PyTorch's bundled RCCL / HIP runtime is not the deployment this path is for)."""
+    env = dict(os.environ, MRT_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", _GROUP_SCRIPT], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "GROUP-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
