@@ -221,6 +221,15 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     const u32 tile_w = P.tiles_x * 8u, tile_h = P.tiles_y * 8u;
     dim3 grid((P.nw + tile_w - 1) / tile_w, (P.local_rows + tile_h - 1) / tile_h, P.k_split);
     const size_t lds = pt_lds_bytes(P, block_threads, scene_in_lds, features);
+    if (features & F_BVH) {         // many-instance scenes: one all-features + BVH instantiation per launch shape
+        if (!scene_in_lds) { if (block_threads != 256u) return hipErrorInvalidConfiguration; hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL | F_BVH>), grid, dim3(256), 0, stream, P, P.blob); }
+        else if (block_threads == 64u) launch_lds<64, F_ALL | F_BVH>(grid, lds, stream, P);
+        else if (block_threads == 256u) launch_lds<256, F_ALL | F_BVH>(grid, lds, stream, P);
+        else if (block_threads == 512u) launch_lds<512, F_ALL | F_BVH>(grid, lds, stream, P);
+        else if (block_threads == 1024u) launch_lds<1024, F_ALL | F_BVH>(grid, lds, stream, P);
+        else return hipErrorInvalidConfiguration;
+        return hipGetLastError();
+    }
     if (scene_in_lds) {
         if (block_threads == 256u) kLds256[features & F_ALL](grid, lds, stream, P);
         else if (block_threads == 64u) kLds64[features & F_ALL](grid, lds, stream, P);
@@ -249,6 +258,10 @@ hipError_t configure_pt(size_t max_lds_bytes)
     MRT_SET(8) MRT_SET(9) MRT_SET(10) MRT_SET(11) MRT_SET(12) MRT_SET(13) MRT_SET(14) MRT_SET(15)
 #undef MRT_SET
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 1024, F_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+    if ((e = set_lds_attr<64, F_ALL | F_BVH>(b)) != hipSuccess) return e;
+    if ((e = set_lds_attr<256, F_ALL | F_BVH>(b)) != hipSuccess) return e;
+    if ((e = set_lds_attr<512, F_ALL | F_BVH>(b)) != hipSuccess) return e;
+    if ((e = set_lds_attr<1024, F_ALL | F_BVH>(b)) != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 512, F_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
 }
 

@@ -6,11 +6,14 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <array>
 
 namespace mrt {
 namespace {
+
+constexpr u32 kBvhMinInstances = 24;    // below this the uniform linear scan is faster than a divergent tree walk
 
 struct H3 { float x, y, z; };
 inline H3 h3(float x, float y, float z) { H3 r = {x, y, z}; return r; }
@@ -286,6 +289,8 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     };
 
     std::vector<u32> rend_tab, inst_tab, instx_tab, mat_tab, mesh_tab, leaf_tab;
+    struct Bound { float c[3]; float r; bool ok; };
+    std::vector<Bound> bounds;           // bounding sphere of every flat instance (ok = false: cannot be bounded)
     std::vector<float> tri_tab, node_tab;
     u32 n_inst_total = 0;
     for (u32 r = 0; r < sc.n_renderer; ++r) {
@@ -375,6 +380,25 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
             }
             inst_tab.insert(inst_tab.end(), ir, ir + INST_WORDS);
             instx_tab.insert(instx_tab.end(), ix, ix + INSTX_WORDS);
+            // bounding sphere in world space: centre = pos, radius = largest object-space extent around pos; valid when the
+            // instance transform preserves lengths (it is a rotation unless the direction is degenerate)
+            Bound bd = {{pos.x, pos.y, pos.z}, 0.0f, o.kind != MRT_KIND_PLANE};
+            if (bd.ok) {
+                double rad = 0.0;
+                if (o.kind == MRT_KIND_SPHERE) rad = fabs((double)o.param[0]);
+                else if (o.kind == MRT_KIND_BOX) rad = 0.5 * sqrt((double)o.param[0] * o.param[0] + (double)o.param[1] * o.param[1] + (double)o.param[2] * o.param[2]);
+                else if (o.kind == MRT_KIND_TRIANGLE) { for (int k = 0; k < 3; ++k) { const double m = sqrt((double)o.param[3 * k] * o.param[3 * k] + (double)o.param[3 * k + 1] * o.param[3 * k + 1] + (double)o.param[3 * k + 2] * o.param[3 * k + 2]); if (!(m <= rad)) rad = m; } }
+                else { for (size_t v = 0; v < (size_t)o.n_tris * 3; ++v) { const float *q = o.tris + v * 3; const double m = sqrt((double)q[0] * q[0] + (double)q[1] * q[1] + (double)q[2] * q[2]); if (!(m <= rad)) rad = m; } }
+                const float *X = xf_tab.data() + (size_t)xf * XF_WORDS;
+                double M[9];
+                for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) { double acc = 0; for (int k = 0; k < 3; ++k) acc += (double)X[XF_R + a * 3 + k] * X[XF_L + k * 3 + b2]; M[a * 3 + b2] = acc; }
+                bool ortho = true;
+                for (int a = 0; a < 3 && ortho; ++a) for (int b2 = 0; b2 < 3; ++b2) { double acc = 0; for (int k = 0; k < 3; ++k) acc += M[a * 3 + k] * M[b2 * 3 + k]; if (!(fabs(acc - (a == b2 ? 1.0 : 0.0)) < 1e-4)) ortho = false; }
+                const double rr = rad * 1.001 + 1e-6;
+                bd.ok = ortho && rr < 1e18 && fabs((double)pos.x) < 1e18 && fabs((double)pos.y) < 1e18 && fabs((double)pos.z) < 1e18;
+                bd.r = (float)rr;
+            }
+            bounds.push_back(bd);
         }
         n_inst_total += o.n_inst;
 
@@ -390,6 +414,59 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     P.n_rend = sc.n_renderer; P.n_inst = n_inst_total; P.n_light = sc.n_light;
     if (sc.n_light) out.features |= 8u;                                              // F_LIGHTS
     P.off_rend = B.align4(); B.w.insert(B.w.end(), rend_tab.begin(), rend_tab.end());
+    // instance BVH: only worth it for many instances; a pure speed-up, the hit it returns is the linear scan's
+    std::vector<u32> lin_list, bvh_inst;
+    std::vector<float> bvh_nodes;
+    {
+        std::vector<u32> elig;
+        for (u32 i = 0; i < n_inst_total; ++i) (bounds[i].ok ? elig : lin_list).push_back(i);
+        if (n_inst_total < kBvhMinInstances || elig.size() < kBvhMinInstances / 2) {
+            lin_list.clear(); elig.clear();
+        } else {
+            struct Build {
+                const std::vector<Bound> &bd; std::vector<float> &nodes; std::vector<u32> &ids;
+                u32 make(std::vector<u32> &v, size_t lo, size_t hi)
+                {
+                    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) {
+                        const Bound &b = bd[v[k]];
+                        if (b.c[a] - b.r < mn[a]) mn[a] = b.c[a] - b.r;
+                        if (b.c[a] + b.r > mx[a]) mx[a] = b.c[a] + b.r;
+                    }
+                    const u32 me = (u32)(nodes.size() / BVH_WORDS);
+                    nodes.resize(nodes.size() + BVH_WORDS);
+                    u32 leaf = 0;
+                    if (hi - lo <= 2) {
+                        leaf = ((u32)(hi - lo) << 24) | (u32)ids.size();
+                        for (size_t k = lo; k < hi; ++k) ids.push_back(v[k]);
+                    } else {
+                        int ax = 0;
+                        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                        for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) { const float c = bd[v[k]].c[a]; if (c < cmn[a]) cmn[a] = c; if (c > cmx[a]) cmx[a] = c; }
+                        for (int a = 1; a < 3; ++a) if (cmx[a] - cmn[a] > cmx[ax] - cmn[ax]) ax = a;
+                        const size_t mid = (lo + hi) / 2;
+                        std::nth_element(v.begin() + lo, v.begin() + mid, v.begin() + hi, [&](u32 x, u32 y) { return bd[x].c[ax] < bd[y].c[ax] || (bd[x].c[ax] == bd[y].c[ax] && x < y); });
+                        make(v, lo, mid);
+                        make(v, mid, hi);
+                    }
+                    float *q = nodes.data() + (size_t)me * BVH_WORDS;
+                    for (int a = 0; a < 3; ++a) { q[BVH_MIN + a] = mn[a]; q[BVH_MAX + a] = mx[a]; }
+                    q[BVH_SKIP] = fbits((u32)(nodes.size() / BVH_WORDS));      // first node after this subtree
+                    q[BVH_LEAF] = fbits(leaf);
+                    return me;
+                }
+            } build{bounds, bvh_nodes, bvh_inst};
+            build.make(elig, 0, elig.size());
+            const u32 n_nodes = (u32)(bvh_nodes.size() / BVH_WORDS);
+            for (u32 k = 0; k < n_nodes; ++k) { float *q = bvh_nodes.data() + (size_t)k * BVH_WORDS; if (bits(q[BVH_SKIP]) >= n_nodes) q[BVH_SKIP] = fbits(BVH_END); }
+            out.features |= 16u;                                                         // F_BVH
+        }
+    }
+    P.n_lin = (u32)lin_list.size(); P.n_bvh_nodes = (u32)(bvh_nodes.size() / BVH_WORDS);
+    out.n_lin = P.n_lin; out.n_bvh_nodes = P.n_bvh_nodes;
+    P.off_lin = B.align4(); B.w.insert(B.w.end(), lin_list.begin(), lin_list.end());
+    P.off_bvh = B.align4(); for (float v : bvh_nodes) B.f(v);
+    P.off_bvhinst = B.align4(); B.w.insert(B.w.end(), bvh_inst.begin(), bvh_inst.end());
     P.off_inst = B.align4(); B.w.insert(B.w.end(), inst_tab.begin(), inst_tab.end());
     P.off_instx = B.align4(); B.w.insert(B.w.end(), instx_tab.begin(), instx_tab.end());
     P.off_xf = B.align4(); for (float v : xf_tab) B.f(v);

@@ -67,6 +67,14 @@ constexpr u32 NO_NODE = 0xffffffffu;
 // NODE: [0..2] 0.5*aabb  [3..5] rel_pos  [6] first child node | first leaf id  [7] count | leaf<<31
 enum : u32 { NODE_HALF = 0, NODE_REL = 3, NODE_FIRST = 6, NODE_COUNT = 7 };
 
+// BVH over renderer instances (scenes with many instances): threaded (stackless) node array in depth-first
+// order.  NODE: [0..2] bmin  [3..5] bmax  [6] skip = next node when this one is missed or is a leaf  [7] leaf word:
+// 0 for an internal node (next = this + 1), else count << 24 | first index into the instance-id list.
+// Instances that cannot be bounded (planes, non-orthonormal transforms) are in the linear list instead.
+constexpr u32 BVH_WORDS = 8;
+enum : u32 { BVH_MIN = 0, BVH_MAX = 3, BVH_SKIP = 6, BVH_LEAF = 7 };
+constexpr u32 BVH_END = 0xffffffffu;
+
 enum : u32 { KIND_SPHERE = 0, KIND_PLANE = 1, KIND_BOX = 2, KIND_TRIANGLE = 3, KIND_MESH = 4 };
 enum : u32 { LK_POINT = 0, LK_DIR = 1 };
 
@@ -89,6 +97,8 @@ struct Params {
     float sky_init[3];       // sky.color * sky.pwr, src/rt.rs:964
     // scene tables
     u32 n_rend, n_light, n_inst;
+    u32 n_lin, n_bvh_nodes;   // instance BVH: linear-list length, node count (0: every instance is scanned linearly)
+    u32 off_lin, off_bvh, off_bvhinst;
     u32 off_rend, off_inst, off_instx, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
     u32 blob_words;
     u32 tiles_x, tiles_y;    // 8x8-pixel wave tiles per workgroup in x and y

@@ -23,7 +23,8 @@ enum : u32 {
     F_TRI = 2u,       // triangle / mesh renderers present
     F_MAPS = 4u,      // some material has a texture map
     F_LIGHTS = 8u,    // the scene has lights (shadow rays + direct term)
-    F_ALL = 15u
+    F_ALL = 15u,
+    F_BVH = 16u       // many instances: a BVH over them replaces most of the linear scan (only built with F_ALL)
 };
 
 // Divergence probe: only the x86 build of tests/emu defines MRT_PROBE(phase); in the kernel it is nothing.
@@ -302,10 +303,47 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, float
     return any;
 }
 
-// RayTracer::closest_hit, src/rt.rs:867-898: every renderer x instance in order, first minimum of
-// the entry distance under f32::total_cmp.  ANY = true answers only Some / None (the shadow query
-// of src/rt.rs:1036).  The loop runs over the flat instance table; each record is fetched one
-// iteration ahead so that its LDS latency is covered by the previous primitive's arithmetic.
+// Renderer::intersect for flat instance i (record words ia, ib): the exact test of the reference, src/rt.rs:725-774
+template <bool ANY, u32 FEAT>
+MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia, const F4 &ib, float &t0, float &t1, i32 &i0, i32 &i1)
+{
+    const float *F = S.U;
+    const Params &P = *S.P;
+    const V3 pos = v3(ia.x, ia.y, ia.z);
+    const u32 tag = f2u(ib.x);
+    const u32 kind = tag & TAG_KIND_MASK;
+    const bool ident = (tag & TAG_IDENT) != 0;
+    const float *X = F + P.off_xf + (tag >> TAG_XF_SHIFT) * XF_WORDS;
+    // n_ray.orig = pos + R*(L*(orig - pos)), n_ray.dir = R*(L*dir), src/rt.rs:729-733
+    const V3 ro = add(pos, xf_vec(X, ident, sub(ray.o, pos)));
+    const bool fast_d = ident && ray.d_ok;
+    V3 rd = ray.d, m = ray.m;
+    float dd = ray.dd;
+    if (!fast_d) {
+        rd = xf_full(X, ray.d);
+        if constexpr (FEAT & F_BOX) m = recip_patched(rd);
+        dd = dot(rd, rd);
+    }
+    t0 = 0.0f; t1 = 0.0f; i0 = -1; i1 = -1;
+    if (kind == KIND_SPHERE) return sphere_isect(ia.w, sub(ro, pos), rd, dd, t0, t1);
+    if (kind == KIND_PLANE) { const bool h = plane_isect(v3(ib.y, ib.z, ib.w), ia.w, ro, rd, t0); t1 = t0; return h; }
+    if ((FEAT & F_BOX) && kind == KIND_BOX) return box_isect(v3(ia.w, ib.y, ib.z), ro, m, pos, t0, t1);
+    if (FEAT & F_TRI) {
+        const float *R = F + P.off_rend + ldu(F, P.off_instx + i * INSTX_WORDS + INSTX_REND) * REND_WORDS;
+        if (kind == KIND_TRIANGLE) {
+            const bool h = tri_isect(add(ld3(R, REND_GEO), pos), ld3(R, REND_GEO + 3), ld3(R, REND_GEO + 6), ro, rd, t0);
+            t1 = t0;
+            return h;
+        }
+        if ((FEAT & F_BOX) && kind == KIND_MESH) return mesh_isect<ANY>(S, ldu(R, REND_GEO), ro, rd, m, pos, t0, i0, t1, i1);
+    }
+    return false;
+}
+
+// RayTracer::closest_hit, src/rt.rs:867-898: every renderer x instance in order, first minimum of the entry distance
+// under f32::total_cmp, i.e. the lexicographic minimum of (total_cmp key, flat instance index) -- which is how the
+// BVH variant, visiting candidates in tree order, returns the very same hit.  ANY = true answers only Some / None
+// (the shadow query of src/rt.rs:1036).  The linear loop fetches each record one iteration ahead of its use.
 template <bool ANY, u32 FEAT>
 MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
 {
@@ -313,58 +351,76 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     const Params &P = *S.P;
     i32 best_key = 0x7fffffff;
     best.rend = -1; best.inst = 0; best.t0 = 0.0f; best.t1 = 0.0f; best.i0 = -1; best.i1 = -1;
-    const u32 n = P.n_inst;
-    if (n == 0) return false;
     const float *I = F + P.off_inst;
-    F4 qa = ld4(I, 0), qb = ld4(I, 4);
-    for (u32 i = 0; i < n; ++i) {
-        const F4 ia = qa, ib = qb;
-        if (i + 1 < n) { qa = ld4(I, (i + 1) * INST_WORDS); qb = ld4(I, (i + 1) * INST_WORDS + 4); }
-        const V3 pos = v3(ia.x, ia.y, ia.z);
-        const u32 tag = f2u(ib.x);
-        const u32 kind = tag & TAG_KIND_MASK;
-        const bool ident = (tag & TAG_IDENT) != 0;
-        const float *X = F + P.off_xf + (tag >> TAG_XF_SHIFT) * XF_WORDS;
-        // Renderer::intersect, src/rt.rs:725-733: n_ray.orig = pos + R*(L*(orig - pos)), n_ray.dir = R*(L*dir)
-        const V3 ro = add(pos, xf_vec(X, ident, sub(ray.o, pos)));
-        const bool fast_d = ident && ray.d_ok;
-        V3 rd = ray.d, m = ray.m;
-        float dd = ray.dd;
-        if (!fast_d) {
-            rd = xf_full(X, ray.d);
-            if constexpr (FEAT & F_BOX) m = recip_patched(rd);
-            dd = dot(rd, rd);
+
+    auto consider = [&](u32 i, const F4 &ia, const F4 &ib) -> bool {
+        float t0, t1;
+        i32 i0, i1;
+        if (!isect_instance<ANY, FEAT>(S, ray, i, ia, ib, t0, t1, i0, i1)) return false;
+        if (ANY) return true;
+        const i32 key = total_key(t0);
+        if (best.rend < 0 || key < best_key || (key == best_key && i < best.inst)) {
+            best_key = key;
+            best.rend = 0; best.inst = i; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
         }
-        float t0 = 0.0f, t1 = 0.0f;
-        i32 i0 = -1, i1 = -1;
-        bool hit;
-        if (kind == KIND_SPHERE) {
-            hit = sphere_isect(ia.w, sub(ro, pos), rd, dd, t0, t1);
-        } else if (kind == KIND_PLANE) {
-            hit = plane_isect(v3(ib.y, ib.z, ib.w), ia.w, ro, rd, t0);
-            t1 = t0;
-        } else if ((FEAT & F_BOX) && kind == KIND_BOX) {
-            hit = box_isect(v3(ia.w, ib.y, ib.z), ro, m, pos, t0, t1);
-        } else if (FEAT & F_TRI) {
-            const float *R = F + P.off_rend + ldu(F, P.off_instx + i * INSTX_WORDS + INSTX_REND) * REND_WORDS;
-            if (kind == KIND_TRIANGLE) {
-                hit = tri_isect(add(ld3(R, REND_GEO), pos), ld3(R, REND_GEO + 3), ld3(R, REND_GEO + 6), ro, rd, t0);
-                t1 = t0;
-            } else if ((FEAT & F_BOX) && kind == KIND_MESH) {
-                hit = mesh_isect<ANY>(S, ldu(R, REND_GEO), ro, rd, m, pos, t0, i0, t1, i1);
-            } else {
-                hit = false;
+        return false;
+    };
+
+    // ---- linear scan: every instance, or (BVH scenes) the ones that cannot be bounded: planes, odd transforms ----
+    const bool bvh = (FEAT & F_BVH) != 0;
+    const u32 n = bvh ? P.n_lin : P.n_inst;
+    if (n) {
+        const float *Lst = F + P.off_lin;
+        u32 cur = bvh ? ldu(Lst, 0) : 0u;
+        F4 qa = ld4(I, cur * INST_WORDS), qb = ld4(I, cur * INST_WORDS + 4);
+        for (u32 j = 0; j < n; ++j) {
+            const F4 ia = qa, ib = qb;
+            const u32 i = cur;
+            if (j + 1 < n) {
+                cur = bvh ? ldu(Lst, j + 1) : j + 1;
+                qa = ld4(I, cur * INST_WORDS); qb = ld4(I, cur * INST_WORDS + 4);
             }
-        } else {
-            hit = false;
+            if (consider(i, ia, ib)) return true;
         }
-        if (hit) {
-            if (ANY) return true;
-            const i32 key = total_key(t0);
-            if (best.rend < 0 || key < best_key) {
-                best_key = key;
-                best.rend = 0; best.inst = i; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
+    }
+
+    // ---- BVH over the bounded instances: threaded depth-first walk, one lane = one walk ----
+    if constexpr (bvh) {
+        // Culling must never drop an instance whose exact test would answer Some.  A node is skipped only when the ray
+        // misses its box grown by 4e-3 x (largest coordinate distance from the origin to the far side of the box): more
+        // than a thousand times the rounding error of the exact tests at that distance.  Rays that are
+        // not finite or not unit length are not culled at all.
+        const V3 o = ray.o, d = ray.d;
+        const bool cull = nzfin(ray.dd) && ray.dd > 0.98f && ray.dd < 1.02f && fabs_(o.x) < 1e18f && fabs_(o.y) < 1e18f && fabs_(o.z) < 1e18f;
+        const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const float *N0 = F + P.off_bvh;
+        u32 node = P.n_bvh_nodes ? 0u : BVH_END;
+        while (node != BVH_END) {
+            const F4 na = ld4(N0, node * BVH_WORDS), nb = ld4(N0, node * BVH_WORDS + 4);
+            const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
+            bool hit_node = true;
+            if (cull) {
+                const V3 bmin = v3(na.x, na.y, na.z), bmax = v3(na.w, nb.x, nb.y);
+                const V3 c = muls(add(bmin, bmax), 0.5f), hh = muls(sub(bmax, bmin), 0.5f);
+                const float ext = fmax_(fmax_(fabs_(o.x - c.x) + hh.x, fabs_(o.y - c.y) + hh.y), fabs_(o.z - c.z) + hh.z);
+                const float mg = 4e-3f * ext + 1e-6f;
+                const float ax = (bmin.x - mg - o.x) * inv.x, bx = (bmax.x + mg - o.x) * inv.x;
+                const float ay = (bmin.y - mg - o.y) * inv.y, by = (bmax.y + mg - o.y) * inv.y;
+                const float az = (bmin.z - mg - o.z) * inv.z, bz = (bmax.z + mg - o.z) * inv.z;
+                const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
+                const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
+                if (tn > tf || tf < 0.0f) hit_node = false;
+                // nothing in a node whose near side lies beyond the current closest hit can win
+                if (!ANY && best.rend >= 0 && best.t0 >= 0.0f && tn > best.t0 + 1e-3f * best.t0 + mg) hit_node = false;
             }
+            if (!hit_node) { node = skip; continue; }
+            if (leaf == 0u) { node = node + 1u; continue; }
+            const u32 cnt = leaf >> 24, first = leaf & 0xffffffu;
+            for (u32 k = 0; k < cnt; ++k) {
+                const u32 i = ldu(F, P.off_bvhinst + first + k);
+                if (consider(i, ld4(I, i * INST_WORDS), ld4(I, i * INST_WORDS + 4))) return true;
+            }
+            node = skip;
         }
     }
     if (best.rend < 0) return false;

@@ -68,4 +68,18 @@ def cases():
     d["scene"]["renderer"] = [{"type": "sphere", "r": 0.5, "mat": {"albedo": [1.7, 0.2, -0.3], "opacity": -2.0, "rough": 2.5, "metal": 0.5, "loss": 0}}]   # out-of-gamut but legal values
     d["rt"]["loss"] = 3.0                                                   # loss.min(1.0) -> every bounce has pwr 0
     out["out_of_range_but_legal_material"] = d
+    # ---- many-instance scenes: the instance BVH must return the linear scan's hit (first minimum in instance order) ----
+    from micro_raytracer_amd import scenes
+    out["bvh_instance_grid_1000"] = scenes.instance_grid(res=(64, 36), sample=2, n=10)
+    out["bvh_minecraft_85"] = scenes.minecraft_like(res=(48, 27), ssaa=1, sample=2)
+    rng = np.random.default_rng(3)
+    boxes = [[[float(x) for x in rng.uniform(-3, 3, 3)], [float(x) for x in rng.normal(size=4)]] for _ in range(40)]
+    spheres = [[[float(x) for x in rng.uniform(-3, 3, 3)], [0, 0, -1, 0]] for _ in range(40)]
+    dup = [[[0.4, 1.0, 0.2], [0, 0, -1, 0]]] * 3                       # coincident instances: exact ties, the first one must win
+    d = scenes.kitchen_sink(res=(48, 32), sample=2)
+    d["scene"]["renderer"] += [{"type": "box", "sizes": [0.4, 0.3, 0.5], "mat": {"rough": 0.6, "albedo": "#a0ffa0"}, "inst": boxes},
+                               {"type": "sphere", "r": 0.25, "mat": {"metal": 0.8}, "inst": spheres},
+                               {"type": "sphere", "r": 0.3, "mat": {"albedo": "#ff2020"}, "inst": dup},
+                               {"type": "sphere", "r": 0.3, "mat": {"albedo": "#2020ff"}, "inst": dup}]
+    out["bvh_mixed_rotated_and_coincident"] = d
     return out

@@ -35,6 +35,13 @@ int emu_pack(const mrt_render_desc *d, uint32_t *blob_words, uint32_t *nw, uint3
     return 0;
 }
 
+int emu_features(const mrt_render_desc *d)
+{
+    Packed pk;
+    if (pack_scene(d, pk, g_err)) return -1;
+    return (int)pk.features;
+}
+
 // the megakernel's per-lane body over every pixel of rows [row0,row1) (frame rows), accumulating into accum[nh][nw][3]
 int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, uint32_t n_samples, uint32_t row0, uint32_t row1,
                uint32_t threads, float *accum, uint64_t *segments)
@@ -62,7 +69,7 @@ int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, ui
             if (y >= row1) break;
             for (uint32_t x = 0; x < pk.nw; ++x) {
                 u32 sg = 0;
-                { RegStash st; LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u; render_pixel<F_ALL>(S, st, x, y, job, sg); }
+                { RegStash st; LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u; if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg); }
                 local += sg;
             }
         }

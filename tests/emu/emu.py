@@ -16,6 +16,7 @@ def lib():
         L = C.CDLL(os.path.join(_HERE, "libemu.so"))
         L.emu_error.restype = C.c_char_p
         L.emu_pack.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
+        L.emu_features.argtypes = [C.c_void_p]
         L.emu_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         L.emu_img.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]

@@ -36,7 +36,7 @@ extern "C" int probe_divergence(const mrt_render_desc *d, uint64_t seed, uint32_
                 g_rec = &rec[l];
                 u32 sg = 0; RegStash st;
                 LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u;
-                render_pixel<F_ALL>(S, st, x, y, job, sg);
+                if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg);
                 g_rec = nullptr;
                 if (rec[l].size() > max_it) max_it = rec[l].size();
             }

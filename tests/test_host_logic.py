@@ -120,6 +120,19 @@ def test_packer_octree_equals_oracle_octree(oracle_mod, emu_mod):
         assert len(oc) <= 512 and oc.sum() == len(oi)
 
 
+def test_instance_bvh_is_built_only_for_many_instances(emu_mod):
+    import ctypes as C
+    from micro_raytracer_amd import scenes
+    L = emu_mod.lib()
+    for desc, want in ((scenes.cornell_box(res=(8, 8)), False), (scenes.instance_grid(res=(8, 8), n=10), True),
+                       (scenes.minecraft_like(res=(8, 8), ssaa=1), True), (scenes.instance_grid(res=(8, 8), n=2), False)):
+        _, h = make_holder(desc)
+        info = (C.c_uint32 * 8)()
+        assert L.emu_pack(C.cast(h.ptr(), C.c_void_p), None, None, None, info) == 0
+        feats = L.emu_features(C.cast(h.ptr(), C.c_void_p))
+        assert bool(feats & 16) == want
+
+
 def test_packer_texture_formats_and_sizes(emu_mod):
     from micro_raytracer_amd import scenes
     _, h = make_holder(scenes.minecraft_like(res=(16, 16), ssaa=1))
