@@ -395,26 +395,34 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         const float *N0 = F + P.off_bvh;
         u32 node = P.n_bvh_nodes ? 0u : BVH_END;
-        while (node != BVH_END) {
-            const F4 na = ld4(N0, node * BVH_WORDS), nb = ld4(N0, node * BVH_WORDS + 4);
-            const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
-            bool hit_node = true;
-            if (cull) {
-                const V3 bmin = v3(na.x, na.y, na.z), bmax = v3(na.w, nb.x, nb.y);
-                const V3 c = muls(add(bmin, bmax), 0.5f), hh = muls(sub(bmax, bmin), 0.5f);
-                const float ext = fmax_(fmax_(fabs_(o.x - c.x) + hh.x, fabs_(o.y - c.y) + hh.y), fabs_(o.z - c.z) + hh.z);
-                const float mg = 4e-3f * ext + 1e-6f;
-                const float ax = (bmin.x - mg - o.x) * inv.x, bx = (bmax.x + mg - o.x) * inv.x;
-                const float ay = (bmin.y - mg - o.y) * inv.y, by = (bmax.y + mg - o.y) * inv.y;
-                const float az = (bmin.z - mg - o.z) * inv.z, bz = (bmax.z + mg - o.z) * inv.z;
-                const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
-                const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
-                if (tn > tf || tf < 0.0f) hit_node = false;
-                // nothing in a node whose near side lies beyond the current closest hit can win
-                if (!ANY && best.rend >= 0 && best.t0 >= 0.0f && tn > best.t0 + 1e-3f * best.t0 + mg) hit_node = false;
+        // "while-while": every lane first walks boxes until it stands on a leaf (cheap iterations, all lanes busy), then
+        // the wavefront runs the expensive exact tests of the leaves together.
+        for (;;) {
+            u32 leaf = 0u, skip = BVH_END;
+            while (node != BVH_END) {
+                const F4 na = ld4(N0, node * BVH_WORDS), nb = ld4(N0, node * BVH_WORDS + 4);
+                skip = f2u(nb.z);
+                leaf = f2u(nb.w);
+                bool hit_node = true;
+                if (cull) {
+                    const V3 bmin = v3(na.x, na.y, na.z), bmax = v3(na.w, nb.x, nb.y);
+                    const V3 c = muls(add(bmin, bmax), 0.5f), hh = muls(sub(bmax, bmin), 0.5f);
+                    const float ext = fmax_(fmax_(fabs_(o.x - c.x) + hh.x, fabs_(o.y - c.y) + hh.y), fabs_(o.z - c.z) + hh.z);
+                    const float mg = 4e-3f * ext + 1e-6f;
+                    const float ax = (bmin.x - mg - o.x) * inv.x, bx = (bmax.x + mg - o.x) * inv.x;
+                    const float ay = (bmin.y - mg - o.y) * inv.y, by = (bmax.y + mg - o.y) * inv.y;
+                    const float az = (bmin.z - mg - o.z) * inv.z, bz = (bmax.z + mg - o.z) * inv.z;
+                    const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
+                    const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
+                    if (tn > tf || tf < 0.0f) hit_node = false;
+                    // nothing in a node whose near side lies beyond the current closest hit can win
+                    if (!ANY && best.rend >= 0 && best.t0 >= 0.0f && tn > best.t0 + 1e-3f * best.t0 + mg) hit_node = false;
+                }
+                if (!hit_node) { node = skip; continue; }
+                if (leaf != 0u) break;
+                node = node + 1u;
             }
-            if (!hit_node) { node = skip; continue; }
-            if (leaf == 0u) { node = node + 1u; continue; }
+            if (node == BVH_END) break;
             const u32 cnt = leaf >> 24, first = leaf & 0xffffffu;
             for (u32 k = 0; k < cnt; ++k) {
                 const u32 i = ldu(F, P.off_bvhinst + first + k);
