@@ -95,10 +95,16 @@ MRT_HD float asin_core_(float a)   // |a| <= 0.5
 
 MRT_HD float acos_(float x)
 {
-    if (x > 0.5f) return 2.0f * asin_core_(sqrt_(0.5f * (1.0f - x)));
-    if (x < -0.5f) return kPi - 2.0f * asin_core_(sqrt_(0.5f * (1.0f + x)));
-    if (x != x) return qnan();
-    return kPiO2 - asin_core_(x);
+    // The contract's three ranges (x > 0.5: 2 asin(sqrt((1-x)/2)); x < -0.5: pi - 2 asin(sqrt((1+x)/2)); else pi/2 - asin(x))
+    // evaluated without branches, so a wavefront pays for one square root and one polynomial instead of all three
+    // arms: (1 - |x|) is the same float as (1 - x) resp. (1 + x), so every lane gets the bits of its own arm.
+    const float ax = fabs_(x);
+    const bool big = ax > 0.5f;
+    const float s = sqrt_(0.5f * (1.0f - ax));
+    const float p = asin_core_(big ? s : x);
+    const float two_p = 2.0f * p;
+    const float r_big = (x > 0.0f) ? two_p : kPi - two_p;
+    return big ? r_big : kPiO2 - p;           // NaN in, NaN out (the comparisons are false, p is NaN)
 }
 
 MRT_HD float atan_pos_(float t)    // t >= 0

@@ -568,6 +568,14 @@ MRT_HD V3 pixel_focus(const Params &P, float cx, float cy)
 }
 
 // the per-sample half of RayTracer::cast, src/rt.rs:916-931
+// lens position of a sample: the two draws of src/rt.rs:916-920
+MRT_HD V3 lens_pos(const Params &P, u32 pk)
+{
+    const float u1 = u32_to_unit(draw_u32(pk, DIM_LENS_X));
+    const float u2 = u32_to_unit(draw_u32(pk, DIM_LENS_Z));
+    return v3(P.cam_pos[0] + (u1 - 0.5f) * P.aprt, P.cam_pos[1], P.cam_pos[2] + (u2 - 0.5f) * P.aprt);
+}
+
 MRT_HD void camera_ray(const Params &P, V3 focus, u32 pk, V3 &o, V3 &d)
 {
     const float u1 = u32_to_unit(draw_u32(pk, DIM_LENS_X));
@@ -665,36 +673,32 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
         if (e > s_stop) e = s_stop;
         st.put(ST_SEND, u2f(e));
     }
-    bool more = job.k < n_chunks;
+    bool alive = job.k < n_chunks;
     V3 csum = v3(0.0f, 0.0f, 0.0f);
-    u32 fresh = 1;
     u32 pk = 0, b = 0;
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
+    V3 o = v3(0, 0, 0), d = v3(0, 1, 0);
     V3 T = v3(1, 1, 1), L = v3(0, 0, 0);
     float pwr = 1.0f;
     u32 seg = 0;
+    if (alive) {                                 // first sample of this lane: every lane of the wavefront is here
+        pk = mix32(pix_key + s * kGold);
+        camera_ray(P, st_get3(st, ST_FOCUS), pk, o, d);
+    }
 
-    // ONE loop with ONE back-edge: a lane whose path ended regenerates at the top of the very next iteration while
-    // its neighbours keep tracing.  (With `continue`s the optimiser threads the known value of `fresh` through the
-    // back-edges and splits this into an outer regeneration loop around an inner segment loop; a wavefront then only
-    // regenerates once all 64 paths have ended.  opaque() hides the value and keeps the loop flat.)
-    for (;;) {
+    // ONE flat loop: an iteration traces one segment; a lane whose path ends draws its next sample's lens position in
+    // the same iteration, and the direction of the next ray -- scattered or fresh from the camera -- goes through ONE
+    // shared normalisation at the bottom.  No lane ever waits for its neighbours' paths to end, and the divergent
+    // regeneration block holds only two hashes and a few adds.
+    while (alive) {
         MRT_PROBE(PH_ITER);
-        if (fresh) {
-            if (!more) break;
-            MRT_PROBE(PH_REGEN);
-            pk = mix32(f2u(st.get(ST_PIXKEY)) + s * kGold);
-            camera_ray(P, st_get3(st, ST_FOCUS), pk, o, d);
-            T = v3(1.0f, 1.0f, 1.0f); L = v3(0.0f, 0.0f, 0.0f);
-            pwr = 1.0f; b = 0;
-            fresh = 0;
-        }
         // ---- RaytraceIterator::next ----
         const RayPre ray = ray_pre<FEAT>(o, d);
         Hit h;
         ++seg;
         V3 contrib = v3(0.0f, 0.0f, 0.0f);
         bool ended = false;
+        V3 X = v3(0.0f, 1.0f, 0.0f);             // un-normalised direction of the next ray
+        V3 base = o;                             // the point it leaves from (hit point, or lens position)
         if (!trace<false, FEAT>(S, ray, h)) {
             // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
             contrib = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
@@ -714,7 +718,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
             // try to refract and lanes that reflect share one pass through the normal / perturbation code; a failed
             // refraction (total internal reflection) takes a second pass as a reflection.
             bool refr = coin(fmin_(1.0f - opacity0, 0.85f), pk, dim_of(b, SL_OPAC_COIN));
-            V3 nd, hp, hn;
+            V3 hp, hn;
             Surf sfh;
             u32 pass = 0;
             for (;;) {
@@ -729,19 +733,19 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                 if (refr) sfh = surf_of<FEAT>(S, h, ob, nhh);
                 float rough = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);            // Ray::reflect / Ray::refract, src/rt.rs:559-589
                 const float opac = refr ? surf_scalar(S, sfh, MAP_OPACITY, MAT_OPACITY) : opacity0;
-                const u32 base = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);     // coin, u1, u2 are consecutive slots
-                if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, base) < (u32)(0.80f * 4294967296.0f)) rough = 1.0f;
-                const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, base + 1u)), u32_to_unit(draw_u32(pk, base + 2u)));
+                const u32 dbase = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);    // coin, u1, u2 are consecutive slots
+                if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, dbase) < (u32)(0.80f * 4294967296.0f)) rough = 1.0f;
+                const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, dbase + 1u)), u32_to_unit(draw_u32(pk, dbase + 2u)));
                 if (refr) {
                     const float eta = 1.0f + 0.5f * surf_scalar(S, sfh, MAP_GLASS, MAT_GLASS);
-                    V3 rdir;
-                    if (refract(d, eta, nn, rdir)) { nd = norm(rdir); break; }
+                    if (refract(d, eta, nn, X)) break;                  // .norm() of src/rt.rs:586 happens at the bottom
                     refr = false;                                       // Vec3f::refract returned None
                     continue;
                 }
-                nd = norm(reflect(d, nn));
+                X = reflect(d, nn);                                     // .norm() of src/rt.rs:569 happens at the bottom
                 break;
             }
+            base = hp;
 
             // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
             const V3 color = surf_color(S, sfh);
@@ -778,11 +782,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                     L = add(L, hadam(T, muls(l_col, pwr)));
                 }
                 T = hadam(T, muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr));
-
-                // Ray::cast, src/rt.rs:551-553, 571
-                o = add(hp, muls(nd, kE));
-                d = nd;
-                pwr = pwr * P.q;
+                pwr = pwr * P.q;                                        // Ray::cast, src/rt.rs:571
                 ++b;
                 if (b > P.bounce) {          // src/rt.rs:1018
                     contrib = add(L, hadam(T, sky_init));
@@ -790,10 +790,10 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                 }
             }
         }
+        bool from_camera = false;
         if (ended) {
             csum = add(csum, contrib);
             ++s;
-            fresh = 1;
             if (s == f2u(st.get(ST_SEND))) {                        // chunk complete: flush its sum
                 u32 j = f2u(st.get(ST_CHUNK));
                 if (direct) {
@@ -804,15 +804,28 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                 }
                 csum = v3(0.0f, 0.0f, 0.0f);
                 j += P.k_split;
-                more = j < n_chunks;
+                alive = j < n_chunks;
                 s = (g0 + j) * kChunk;
                 u32 e = s + kChunk;
                 if (e > s_stop) e = s_stop;
                 st.put(ST_CHUNK, u2f(j));
                 st.put(ST_SEND, u2f(e));
             }
+            if (alive) {                                            // next sample: RayTracer::cast, src/rt.rs:916-922
+                MRT_PROBE(PH_REGEN);
+                pk = mix32(f2u(st.get(ST_PIXKEY)) + s * kGold);
+                base = lens_pos(P, pk);
+                X = sub(st_get3(st, ST_FOCUS), base);               // new_dir before .norm()
+                T = v3(1.0f, 1.0f, 1.0f); L = v3(0.0f, 0.0f, 0.0f);
+                pwr = 1.0f; b = 0;
+                from_camera = true;
+            }
         }
-        fresh = opaque(fresh);
+        // next ray: dir = X.norm(), orig = base + dir * E  (Ray::cast src/rt.rs:551-553; cast_default :555-557)
+        V3 nd = norm(X);
+        if (from_camera && !(P.cam_ident && nzfin3(nd))) nd = m3mul(P.cam_R, m3mul(P.cam_L, nd));   // rot_y * (look * new_dir), src/rt.rs:930
+        o = add(base, muls(nd, kE));
+        d = nd;
     }
     if (direct) {
         const V3 acc = st_get3(st, ST_ACC);
