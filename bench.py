@@ -64,6 +64,23 @@ def cpu_baseline(render, seconds_target=12.0):
             "sample": f"rows {rows[0]}..{rows[1]} of the {nw}x{nh} frame, {spp2} spp, {t2:.1f} s"}
 
 
+VALU_ISSUE_PEAK_GINSTR = 1171.0   # G wave-instructions/s of independent v_mul/v_add/v_fma measured on MI355X
+
+
+def pmc_profile(workload, world):
+    """The newest committed rocprofv3 PMC summary of this workload (profiles/*_summary.json), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("n_gpus", 1) == world:
+            best = (d, os.path.basename(f))
+    return best
+
+
 def pmc_traffic(workload, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/*_summary.json, written by profiles/summarize.py: FETCH_SIZE doubled per the gfx950 note of
@@ -185,6 +202,14 @@ def main():
         img_bytes = 15.0 * nw * nh + (0 if (nw, nh) == tuple(render.frame.res) else 3.0 * nw * nh + 2 * 12.0 * nw * render.frame.res[1] + 3.0 * render.frame.res[0] * render.frame.res[1])
         line["img"] = {"kernels_ms": ist["img_ms"], "algorithmic_bytes": img_bytes, "GBps": img_bytes / (ist["img_ms"] * 1e-3) / 1e9 if ist["img_ms"] > 0 else None,
                        "out": [int(img.shape[1]), int(img.shape[0])]}
+        prof = pmc_profile(args.workload, world) if not args.spp else None
+        if prof and "valu_wave_instr" in prof[0].get("derived", {}):
+            dv, ms = prof[0]["derived"], prof[0].get("avg_ms", 0.0)
+            if ms > 0:
+                g = dv["valu_wave_instr"] / (ms * 1e-3) / 1e9
+                line["valu"]["pmc"] = {"source": prof[1], "valu_wave_instr_per_launch": dv["valu_wave_instr"], "kernel_ms": ms,
+                                       "G_wave_instr_per_s": g, "frac_of_measured_issue_peak": g / VALU_ISSUE_PEAK_GINSTR,
+                                       "lane_utilisation": dv.get("lane_utilisation")}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(render)
         print(json.dumps(line), flush=True)
