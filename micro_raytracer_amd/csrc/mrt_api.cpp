@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -54,8 +55,10 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;                                                          // rccl.h:339
+    std::mutex mu;
     bool load(std::string &err)
     {
+        std::lock_guard<std::mutex> lock(mu);
         if (lib) return true;
         for (const char *name : {"/opt/rocm/lib/librccl.so", "librccl.so", "librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
         if (!lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }

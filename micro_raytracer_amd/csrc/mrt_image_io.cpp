@@ -12,15 +12,14 @@
 
 namespace {
 
-uint32_t crc_table[256];
-bool crc_ready = false;
+struct CrcTable {
+    uint32_t t[256];
+    CrcTable() { for (uint32_t i = 0; i < 256; ++i) { uint32_t k = i; for (int j = 0; j < 8; ++j) k = (k & 1) ? 0xedb88320u ^ (k >> 1) : k >> 1; t[i] = k; } }
+};
 uint32_t crc32(const uint8_t *p, size_t n, uint32_t c = 0xffffffffu)
 {
-    if (!crc_ready) {
-        for (uint32_t i = 0; i < 256; ++i) { uint32_t k = i; for (int j = 0; j < 8; ++j) k = (k & 1) ? 0xedb88320u ^ (k >> 1) : k >> 1; crc_table[i] = k; }
-        crc_ready = true;
-    }
-    for (size_t i = 0; i < n; ++i) c = crc_table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    static const CrcTable table;          // thread-safe one-time initialisation
+    for (size_t i = 0; i < n; ++i) c = table.t[(c ^ p[i]) & 0xff] ^ (c >> 8);
     return c;
 }
 void be32(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
