@@ -599,6 +599,9 @@ MRT_HD u32 opaque(u32 x)
     return x;
 }
 
+// gen_bool(0.80) of src/rt.rs:564,579 takes the f64 literal 0.80: the threshold is floor(0.8 * 2^32), not the f32 0.8
+constexpr u32 kThr080 = 3435973836u;
+
 MRT_HD u32 dim_of(u32 bounce, u32 slot) { return DIM_BOUNCE0 + bounce * DIMS_PER_BOUNCE + slot; }
 
 // Bernoulli draw that only touches the generator when the outcome is open (p == 0 is always false, p == 1 always
@@ -734,7 +737,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                 float rough = surf_scalar(S, sfh, MAP_ROUGH, MAT_ROUGH);            // Ray::reflect / Ray::refract, src/rt.rs:559-589
                 const float opac = refr ? surf_scalar(S, sfh, MAP_OPACITY, MAT_OPACITY) : opacity0;
                 const u32 dbase = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);    // coin, u1, u2 are consecutive slots
-                if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, dbase) < (u32)(0.80f * 4294967296.0f)) rough = 1.0f;
+                if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, dbase) < kThr080) rough = 1.0f;
                 const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, dbase + 1u)), u32_to_unit(draw_u32(pk, dbase + 2u)));
                 if (refr) {
                     const float eta = 1.0f + 0.5f * surf_scalar(S, sfh, MAP_GLASS, MAT_GLASS);

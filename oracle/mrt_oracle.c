@@ -141,6 +141,9 @@ enum { DIM_LENS_X = 0, DIM_LENS_Z = 1, DIM_BOUNCE0 = 2, DIMS_PER_BOUNCE = 8 };
 enum { SL_REFL_COIN = 0, SL_REFL_U1, SL_REFL_U2, SL_OPAC_COIN, SL_REFR_COIN, SL_REFR_U1, SL_REFR_U2, SL_EMIT_COIN };
 static inline uint32_t dim_of(uint32_t bounce, uint32_t slot) { return DIM_BOUNCE0 + bounce * DIMS_PER_BOUNCE + slot; }
 
+/* gen_bool(0.80) at src/rt.rs:564,579 takes the f64 literal 0.80: threshold floor(0.8 * 2^32), not the f32 0.8 */
+#define THR_080 3435973836u
+
 /* rand 0.8.5 Bernoulli: p == 1 always true without a draw; else u < p * 2^N */
 static inline int bernoulli(float p, uint32_t u)
 {
@@ -613,7 +616,7 @@ static ray_t ray_reflect(const orc_ctx *c, const ray_t *self, const hit_t *hit, 
     float rough = hit_get_rough(c, hit);
     float opacity = hit_get_opacity(c, hit);
     uint32_t b = self->bounce;
-    if (hit->obj->mat.metal == 0.0f && opacity != 0.0f && bernoulli(0.80f, orc_draw_u32(pk, dim_of(b, SL_REFL_COIN)))) rough = 1.0f;
+    if (hit->obj->mat.metal == 0.0f && opacity != 0.0f && (orc_draw_u32(pk, dim_of(b, SL_REFL_COIN)) < THR_080)) rough = 1.0f;
     v3 norm = rt_rand(hit->norm, rough, orc_draw_f32(pk, dim_of(b, SL_REFL_U1)), orc_draw_f32(pk, dim_of(b, SL_REFL_U2)));
     v3 dir = v3_norm(v3_reflect(self->dir, norm));
     return ray_cast(ray_point(self), dir, self->pwr * (1.0f - f_min(c->loss, 1.0f)), self->bounce + 1);
@@ -625,7 +628,7 @@ static int ray_refract(const orc_ctx *c, const ray_t *self, const hit_t *hit, ui
     float rough = hit_get_rough(c, hit);
     float opacity = hit_get_opacity(c, hit);
     uint32_t b = self->bounce;
-    if (hit->obj->mat.metal == 0.0f && opacity != 0.0f && bernoulli(0.80f, orc_draw_u32(pk, dim_of(b, SL_REFR_COIN)))) rough = 1.0f;
+    if (hit->obj->mat.metal == 0.0f && opacity != 0.0f && (orc_draw_u32(pk, dim_of(b, SL_REFR_COIN)) < THR_080)) rough = 1.0f;
     v3 norm = rt_rand(hit->norm, rough, orc_draw_f32(pk, dim_of(b, SL_REFR_U1)), orc_draw_f32(pk, dim_of(b, SL_REFR_U2)));
     float eta = 1.0f + 0.5f * hit_get_glass(c, hit);
     v3 d;
