@@ -1,0 +1,41 @@
+"""CPU-side sanitizer run (not collected by pytest): the oracle, the host packer and the kernel headers compiled for
+x86 with -fsanitize=address,undefined, driven over random scenes, the edge cases and the asset-heavy scenes.
+
+    mkdir -p build/san
+    gcc -g -O1 -fsanitize=address,undefined -fPIC -std=gnu11 -ffp-contract=off -pthread -shared -o build/san/liboracle.so oracle/mrt_oracle.c -lm
+    g++ -g -O1 -fsanitize=address,undefined -std=c++17 -fPIC -ffp-contract=off -w -pthread -shared -o build/san/libemu.so tests/emu/emu.cpp micro_raytracer_amd/csrc/mrt_pack.cpp
+    LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python3 tests/sanitize_cpu.py
+
+GPU AddressSanitizer is not available on the pool; the device code is covered through this x86 build.
+Last run: 77 scenes, no report.
+"""
+import sys, os, ctypes as C, numpy as np
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
+import oracle.oracle as O
+import emu.emu as E
+# point the bindings at the sanitizer builds
+O._LIB=None; E._LIB=None
+O._HERE=ROOT+'/build/san'; 
+_orig_cdll=C.CDLL
+def cdll(path,*a,**k):
+    if path.endswith('liboracle.so'): path=ROOT+'/build/san/liboracle.so'
+    if path.endswith('libemu.so'): path=ROOT+'/build/san/libemu.so'
+    return _orig_cdll(path,*a,**k)
+C.CDLL=cdll
+import subprocess
+subprocess.check_call=lambda *a,**k: 0
+from test_fuzz_scenes import random_scene, _check
+from edge_cases import cases
+from conftest import make_holder
+from micro_raytracer_amd import scenes
+n=0
+descs=[random_scene(s) for s in range(60)]+list(cases().values())+[scenes.minecraft_like(res=(24,16),ssaa=1,sample=1), scenes.mesh_scene(res=(24,16),sample=1), scenes.kitchen_sink(res=(24,16),sample=2)]
+for d in descs:
+    render,h=make_holder(d); spp=render.rt.sample
+    o=O.Oracle(h, seed=3); o.execute(spp, threads=3); ref,_=o.accum()
+    got,_=E.render(h,3,spp,threads=3)
+    _check(got,ref,spp)
+    o.set_accum(got,spp); ss,out=E.img(h,got,spp); assert np.array_equal(out,o.img())
+    o.close(); n+=1
+print("sanitizer run ok:", n, "scenes")
