@@ -173,3 +173,23 @@ def test_img_before_samples_is_an_error():
     s.execute(render, n_samples=0)
     with pytest.raises(MrtError):
         s.img()
+
+
+def test_more_shards_than_row_blocks_and_context_churn():
+    """Shards that own no rows are legal (a tiny frame on many GPUs); contexts can be created and destroyed freely."""
+    from micro_raytracer_amd import Sampler, scenes
+    render, _ = make_holder(scenes.cornell_box(res=(24, 8), sample=2))
+    whole, _ = _gpu_render(render, 2).accum()
+    out = np.zeros_like(whole)
+    for r in range(4):
+        s = _gpu_render(render, 2, shard_index=r, shard_count=4)
+        loc, rows = s.accum_local()
+        assert len(rows) == (8 if r == 0 else 0)
+        out[rows] = loc
+        assert s.accum()[1] == 2
+        s.close()
+    assert np.array_equal(out, whole)
+    for _ in range(60):
+        s = Sampler(seed=1)
+        s.execute(render, n_samples=1)
+        s.close()
