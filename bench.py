@@ -209,7 +209,9 @@ def main():
                 g = dv["valu_wave_instr"] / (ms * 1e-3) / 1e9
                 line["valu"]["pmc"] = {"source": prof[1], "valu_wave_instr_per_launch": dv["valu_wave_instr"], "kernel_ms": ms,
                                        "G_wave_instr_per_s": g, "frac_of_measured_issue_peak": g / VALU_ISSUE_PEAK_GINSTR,
-                                       "lane_utilisation": dv.get("lane_utilisation")}
+                                       "lane_utilisation": dv.get("lane_utilisation"),
+                                       "fp32_tflops_issued": dv.get("fp32_tflops_issued"), "fp32_tflops_useful": dv.get("fp32_tflops_useful"),
+                                       "instruction_mix": dv.get("mix")}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(render)
         print(json.dumps(line), flush=True)

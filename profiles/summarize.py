@@ -32,6 +32,10 @@ d = {}
 if "SQ_INSTS_VALU" in pmc:
     d["valu_wave_instr"] = pmc["SQ_INSTS_VALU"]
     d["lane_utilisation"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+if "SQ_INSTS_VALU_FLOPS_FP32" in pmc and "SQ_INSTS_VALU" in pmc:
+    # dynamic instruction mix (wave-instructions per launch); FLOPS_FP32 counts add + mul + 2 x fma + trans
+    d["mix"] = {k.replace("SQ_INSTS_VALU_", "").lower(): pmc[k] / pmc["SQ_INSTS_VALU"] for k in pmc if k.startswith("SQ_INSTS_VALU_")}
+    d["fp32_flop_wave_instr"] = pmc["SQ_INSTS_VALU_FLOPS_FP32"]
 if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc:
     d["wait_any_frac"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
     d["wait_inst_any_frac"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
@@ -42,6 +46,10 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     d["hbm_read_bytes"] = 2.0 * pmc["FETCH_SIZE"] * 1024.0
     d["hbm_write_bytes"] = pmc["WRITE_SIZE"] * 1024.0
     d["hbm_traffic_bytes"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
+if "fp32_flop_wave_instr" in d and out.get("avg_ms") and "lane_utilisation" in d:
+    t = out["avg_ms"] * 1e-3
+    d["fp32_tflops_issued"] = d["fp32_flop_wave_instr"] * 64 / t / 1e12                       # every lane of an issued instruction
+    d["fp32_tflops_useful"] = d["fp32_tflops_issued"] * d["lane_utilisation"]               # active lanes only
 out["derived"] = d
 json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
