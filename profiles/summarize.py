@@ -19,13 +19,16 @@ if ks:
             out["calls"] = int(r["Calls"])
             out["avg_ms"] = float(r["AverageNs"]) / 1e6
             out["pct_gpu_time"] = float(r["Percentage"])
-pmc = collections.defaultdict(float)
+pmc = {}
 meta = {}
-for f in glob.glob(f"gpurun_out/{tag}_pmc_*/*/*_counter_collection.csv"):
+for f in sorted(glob.glob(f"gpurun_out/{tag}_pmc_*/*/*_counter_collection.csv")):
+    one = collections.defaultdict(float)          # one --pmc pass = one launch of the kernel
     for r in csv.DictReader(open(f)):
         if "pt_megakernel" in r["Kernel_Name"]:
-            pmc[r["Counter_Name"]] += float(r["Counter_Value"])
+            one[r["Counter_Name"]] += float(r["Counter_Value"])
             meta = {k: r[k] for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
+    for k, v in one.items():
+        pmc.setdefault(k, v)                      # a counter collected in several passes: keep the first pass
 out["pmc_per_launch"] = dict(pmc)
 out["dispatch"] = meta
 d = {}
