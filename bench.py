@@ -32,6 +32,12 @@ WORKLOADS = {
     "cornell_1080p_1024spp_b8": (dict(kind="cornell_box", res=(1920, 1080), bounce=8), 1024),
     "cornell_512_64spp_b8": (dict(kind="cornell_box", res=(512, 512), bounce=8), 64),           # BASELINE.json configs[1]
     "cornell2_4k_64spp_b16": (dict(kind="cornell_box2", res=(1920, 1080), ssaa=2, bounce=16), 64),  # configs[2] geometry
+    # the BASELINE.json configs at their full sizes (one step = the whole render)
+    "c1_default_256_1spp_b1": (dict(kind="default_scene", res=(256, 256), ssaa=1, bounce=1), 1),
+    "c3_cornell2_1080p_ssaa2_1024spp_b16": (dict(kind="cornell_box2", res=(1920, 1080), ssaa=2, bounce=16), 1024),
+    "c4_cornell2_2160p_1024spp_b16": (dict(kind="cornell_box2", res=(3840, 2160), ssaa=1, bounce=16), 1024),
+    "c5_mesh_1080p_512spp": (dict(kind="mesh_scene", res=(1920, 1080), ssaa=1, bounce=8), 512),
+    "c5_minecraft_1080p_ssaa2_512spp": (dict(kind="minecraft_like", res=(1920, 1080), ssaa=2, bounce=8), 512),
 }
 
 
@@ -183,7 +189,7 @@ def main():
             "metric": "Msamples/sec (res x spp)", "value": samples / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scene": "Cornell box (5 planes + 5 spheres, App. B.2 of SURVEY.md)",
+            "config": {"workload": args.workload, "scene": spec["kind"],
                        "res": [render.frame.res[0], render.frame.res[1]], "ssaa": render.frame.ssaa, "spp_per_step": spp,
                        "bounce": render.rt.bounce, "samples_per_step": float(nw) * nh * spp,
                        "sharding": f"rows, block-cyclic x{ss.shard_rows}, {world} rank(s), 1 RCCL gather/step" if world > 1 else "single GPU"},
