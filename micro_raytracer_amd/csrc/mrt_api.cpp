@@ -195,9 +195,10 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
-    const size_t blob_bytes = (size_t)c->pk.blob.size() * 4;
-    if ((e = hipMalloc((void **)&c->d_blob, blob_bytes ? blob_bytes : 16)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
-    if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), blob_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
+    const size_t all_bytes = (size_t)c->pk.blob.size() * 4;
+    if ((e = hipMalloc((void **)&c->d_blob, all_bytes ? all_bytes : 16)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
+    if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), all_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
+    const size_t blob_bytes = (size_t)c->pk.P.lds_words * 4;      // the part a workgroup stages in LDS
     {
         const u32 n_blocks = (nh + c->shard_rows - 1) / c->shard_rows;
         c->padded_rows = ((n_blocks + shard_count - 1) / shard_count) * c->shard_rows;

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
     const float *F;
     if (SCENE_IN_LDS) {
         const uint4 *g = reinterpret_cast<const uint4 *>(P.blob);
-        const u32 n4 = P.blob_words >> 2;
+        const u32 n4 = P.lds_words >> 2;
         for (u32 i = threadIdx.x; i < n4; i += blockDim.x) lds_blob[i] = g[i];
         __syncthreads();
         F = reinterpret_cast<const float *>(lds_blob);
@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
 #else
         S.U = F;
 #endif
+        S.G = reinterpret_cast<const float *>(blob_g);
         S.P = &P;
         LaneJob job;
         job.k = blockIdx.z;
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         if constexpr (lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
             LdsStash<BLOCK_THREADS> st;
-            st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + ((P.blob_words + 3u) >> 2)) + threadIdx.x);
+            st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + ((P.lds_words + 3u) >> 2)) + threadIdx.x);
             render_pixel<FEAT>(S, st, x, y, job, segments);
         } else {
             RegStash st;
@@ -210,7 +211,7 @@ static const LaunchFn kLds64[16] = MRT_ALL_FEATS(64);
 size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 features)
 {
     if (!scene_in_lds) return 0;
-    size_t lds = (size_t)P.blob_words * 4u;
+    size_t lds = (size_t)P.lds_words * 4u;
     if (lds_stash_for(scene_in_lds, (int)block_threads)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
     return lds;
 }

@@ -33,6 +33,24 @@ MRT_HD float sqrt_(float x) { return __builtin_sqrtf(x); }     // IEEE correctly
 MRT_HD float floor_(float x) { return __builtin_floorf(x); }
 MRT_HD float trunc_(float x) { return __builtin_truncf(x); }
 MRT_HD float recip_(float x) { return 1.0f / x; }              // f32::recip
+// Approximate reciprocal (1 ulp, one instruction) for values that only steer conservative culling, never a result.
+MRT_HD float rcp_fast(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// a * b + c in one instruction where the hardware has it; like rcp_fast, only for culling arithmetic
+MRT_HD float fma_fast(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
 
 constexpr float kPi = 3.14159274101257324f;    // std::f32::consts::PI
 constexpr float kPiO2 = 1.57079637050628662f;

@@ -150,6 +150,113 @@ void build_octree(const float *tris, u32 n_tris, OctreeFlat &out)
     flatten(root, 0, out);
 }
 
+// ---- triangle BVH of a mesh (mrt_scene.h): a pure accelerator, any valid tree gives the same render ----
+// Top-down sweep SAH on triangle centroids (median split above kSahMax triangles per node), leaves of at most
+// leaf_max items, nodes in depth-first order with skip links; `order` receives the triangles in leaf order.
+namespace {
+constexpr u32 kTbvhLeaf = 4;
+constexpr size_t kSahMax = 8192;
+struct TriBox { float mn[3], mx[3], c[3]; };
+struct TbvhBuild {
+    const std::vector<TriBox> &tb;
+    std::vector<float> &nodes;
+    std::vector<u32> &order;
+    u32 leaf_max;
+    static double area(const float *mn, const float *mx)
+    {
+        const double x = (double)mx[0] - mn[0], y = (double)mx[1] - mn[1], z = (double)mx[2] - mn[2];
+        return x * y + y * z + z * x;
+    }
+    void make(std::vector<u32> &v, size_t lo, size_t hi)
+    {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) {
+            const TriBox &b = tb[v[k]];
+            if (b.mn[a] < mn[a]) mn[a] = b.mn[a];
+            if (b.mx[a] > mx[a]) mx[a] = b.mx[a];
+        }
+        const u32 me = (u32)(nodes.size() / BVH_WORDS);
+        nodes.resize(nodes.size() + BVH_WORDS);
+        const size_t n = hi - lo;
+        u32 leaf = 0;
+        size_t mid = 0;
+        int best_ax = -1;
+        if (n > 2) {
+            if (n > kSahMax) {
+                float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) { const float c = tb[v[k]].c[a]; if (c < cmn[a]) cmn[a] = c; if (c > cmx[a]) cmx[a] = c; }
+                best_ax = 0;
+                for (int a = 1; a < 3; ++a) if (cmx[a] - cmn[a] > cmx[best_ax] - cmn[best_ax]) best_ax = a;
+                mid = (lo + hi) / 2;
+            } else {
+                // cost of a split = area(L) * |L| + area(R) * |R| (triangle tests weighted by hit probability)
+                double best = INFINITY;
+                std::vector<double> right(n);
+                for (int a = 0; a < 3; ++a) {
+                    std::sort(v.begin() + lo, v.begin() + hi, [&](u32 x, u32 y) { return tb[x].c[a] < tb[y].c[a] || (tb[x].c[a] == tb[y].c[a] && x < y); });
+                    float rmn[3] = {INFINITY, INFINITY, INFINITY}, rmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (size_t k = n; k-- > 1;) {
+                        const TriBox &b = tb[v[lo + k]];
+                        for (int q = 0; q < 3; ++q) { if (b.mn[q] < rmn[q]) rmn[q] = b.mn[q]; if (b.mx[q] > rmx[q]) rmx[q] = b.mx[q]; }
+                        right[k] = area(rmn, rmx) * (double)(n - k);
+                    }
+                    float lmn[3] = {INFINITY, INFINITY, INFINITY}, lmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (size_t k = 1; k < n; ++k) {
+                        const TriBox &b = tb[v[lo + k - 1]];
+                        for (int q = 0; q < 3; ++q) { if (b.mn[q] < lmn[q]) lmn[q] = b.mn[q]; if (b.mx[q] > lmx[q]) lmx[q] = b.mx[q]; }
+                        const double cost = area(lmn, lmx) * (double)k + right[k];
+                        if (cost < best) { best = cost; best_ax = a; mid = lo + k; }
+                    }
+                }
+                // a small node stays a leaf when splitting does not pay for the two extra box tests
+                if (n <= leaf_max && !(best + 1.0 * area(mn, mx) < area(mn, mx) * (double)n)) best_ax = -1;
+            }
+        }
+        if (best_ax < 0) {
+            leaf = ((u32)n << 24) | (u32)order.size();
+            for (size_t k = lo; k < hi; ++k) order.push_back(v[k]);
+        } else {
+            if (n > kSahMax) std::nth_element(v.begin() + lo, v.begin() + mid, v.begin() + hi, [&](u32 x, u32 y) { return tb[x].c[best_ax] < tb[y].c[best_ax] || (tb[x].c[best_ax] == tb[y].c[best_ax] && x < y); });
+            else if (best_ax != 2) std::sort(v.begin() + lo, v.begin() + hi, [&](u32 x, u32 y) { return tb[x].c[best_ax] < tb[y].c[best_ax] || (tb[x].c[best_ax] == tb[y].c[best_ax] && x < y); });
+            make(v, lo, mid);
+            make(v, mid, hi);
+        }
+        float *q = nodes.data() + (size_t)me * BVH_WORDS;
+        for (int a = 0; a < 3; ++a) {
+            // centre / half size, rounded so that the stored box contains [mn, mx]
+            const float c = 0.5f * mn[a] + 0.5f * mx[a];
+            float h = fmaxf(mx[a] - c, c - mn[a]);
+            h = nextafterf(h, INFINITY);
+            q[BVH_C + a] = c; q[BVH_H + a] = h;
+        }
+        q[BVH_SKIP] = fbits((u32)(nodes.size() / BVH_WORDS));      // first node after this subtree (mesh-relative)
+        q[BVH_LEAF] = fbits(leaf);
+    }
+};
+}  // namespace
+
+bool build_tbvh(const float *tris, u32 n_tris, std::vector<float> &nodes, std::vector<u32> &order)
+{
+    nodes.clear(); order.clear();
+    if (n_tris == 0 || n_tris >= (1u << 24)) return false;
+    std::vector<TriBox> tb(n_tris);
+    for (u32 t = 0; t < n_tris; ++t) {
+        const float *p = tris + (size_t)t * 9;
+        TriBox &b = tb[t];
+        for (int a = 0; a < 3; ++a) {
+            const float x = p[a], y = p[3 + a], z = p[6 + a];
+            if (!(fabsf(x) <= 1e6f) || !(fabsf(y) <= 1e6f) || !(fabsf(z) <= 1e6f)) return false;     // also refuses NaN
+            b.mn[a] = fminf(x, fminf(y, z)); b.mx[a] = fmaxf(x, fmaxf(y, z));
+            b.c[a] = (float)(((double)x + y + z) / 3.0);
+        }
+    }
+    std::vector<u32> v(n_tris);
+    for (u32 t = 0; t < n_tris; ++t) v[t] = t;
+    TbvhBuild build{tb, nodes, order, kTbvhLeaf};
+    build.make(v, 0, n_tris);
+    return true;
+}
+
 // image 0.24 imageops::sample: per-output-index taps of horizontal_sample / vertical_sample
 void lanczos3_taps(u32 src, u32 dst, ResampleTaps &out)
 {
@@ -289,9 +396,10 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     };
 
     std::vector<u32> rend_tab, inst_tab, instx_tab, mat_tab, mesh_tab, leaf_tab;
-    struct Bound { float c[3]; float r; bool ok; };
-    std::vector<Bound> bounds;           // bounding sphere of every flat instance (ok = false: cannot be bounded)
-    std::vector<float> tri_tab, node_tab;
+    struct Bound { float mn[3], mx[3]; bool ok; };
+    std::vector<Bound> bounds;           // world-space box of every flat instance (ok = false: cannot be bounded)
+    std::vector<float> tri_tab, node_tab, tbvh_tab;
+    std::vector<u32> memb_tab, membe_tab, parent_tab;
     u32 n_inst_total = 0;
     for (u32 r = 0; r < sc.n_renderer; ++r) {
         const mrt_renderer &o = sc.renderer[r];
@@ -336,19 +444,60 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
             }
             const u32 node0 = (u32)(node_tab.size() / NODE_WORDS);
             const u32 leaf0 = (u32)leaf_tab.size();
-            // node-relative child indices -> absolute node indices
-            for (size_t n = 0; n < oc.nodes.size() / NODE_WORDS; ++n) {
-                float *q = oc.nodes.data() + n * NODE_WORDS;
-                if (!(bits(q[NODE_COUNT]) & 0x80000000u)) q[NODE_FIRST] = fbits(bits(q[NODE_FIRST]) + node0);
+            const u32 tri0 = (u32)(tri_tab.size() / TRI_WORDS);
+            const u32 n_oc_nodes = (u32)(oc.nodes.size() / NODE_WORDS);
+            // triangle BVH: triangles are stored in its leaf order (new id -> old id in `order`)
+            std::vector<float> tbn;
+            std::vector<u32> order, new_of(o.n_tris);
+            bool tb_ok = build_tbvh(o.tris, o.n_tris, tbn, order);
+            tb_ok = tb_ok && oc.root != NO_NODE && n_oc_nodes <= (1u << (32 - MEMB_SLOT_BITS)) && oc.leaf_ids.size() <= MEMB_SLOT_MASK;
+            if (!tb_ok) { order.resize(o.n_tris); for (u32 t = 0; t < o.n_tris; ++t) order[t] = t; tbn.clear(); }
+            for (u32 t = 0; t < o.n_tris; ++t) new_of[order[t]] = t;
+            // membership of every triangle: (octree leaf, slot) of each occurrence in the leaf lists; parents of the nodes
+            std::vector<std::vector<u32>> memb(tb_ok ? o.n_tris : 0);
+            const size_t parent0 = parent_tab.size();
+            parent_tab.resize(parent0 + n_oc_nodes, NO_NODE);
+            for (u32 n = 0; n < n_oc_nodes; ++n) {
+                float *q = oc.nodes.data() + (size_t)n * NODE_WORDS;
+                const u32 first = bits(q[NODE_FIRST]), cw = bits(q[NODE_COUNT]);
+                if (cw & 0x80000000u) {
+                    if (tb_ok) for (u32 k = 0; k < (cw & 0x7fffffffu); ++k) memb[new_of[oc.leaf_ids[first + k]]].push_back((n << MEMB_SLOT_BITS) | (first + k));
+                } else {
+                    for (u32 k = 0; k < cw; ++k) parent_tab[parent0 + first + k] = node0 + n;
+                    q[NODE_FIRST] = fbits(first + node0);      // node-relative child indices -> absolute node indices
+                }
             }
-            mesh_tab.push_back((u32)(tri_tab.size() / TRI_WORDS));
+            for (u32 t = 0; tb_ok && t < o.n_tris; ++t) if (memb[t].size() > 255u) tb_ok = false;
+            if (tb_ok && membe_tab.size() + oc.leaf_ids.size() >= (1u << 24)) tb_ok = false;
+            const u32 tb0 = (u32)(tbvh_tab.size() / BVH_WORDS);
+            if (tb_ok) {
+                const u32 nn = (u32)(tbn.size() / BVH_WORDS);
+                for (u32 k = 0; k < nn; ++k) {
+                    float *q = tbn.data() + (size_t)k * BVH_WORDS;
+                    const u32 skip = bits(q[BVH_SKIP]);
+                    q[BVH_SKIP] = fbits(skip >= nn ? BVH_END : tb0 + skip);
+                }
+                tbvh_tab.insert(tbvh_tab.end(), tbn.begin(), tbn.end());
+            }
+            for (u32 t = 0; t < o.n_tris; ++t) {
+                u32 head = 0;
+                if (tb_ok) {
+                    std::sort(memb[t].begin(), memb[t].end(), [](u32 a, u32 b) { return (a & MEMB_SLOT_MASK) < (b & MEMB_SLOT_MASK); });
+                    head = ((u32)memb[t].size() << 24) | (u32)membe_tab.size();
+                    membe_tab.insert(membe_tab.end(), memb[t].begin(), memb[t].end());
+                }
+                memb_tab.push_back(head);
+            }
+            mesh_tab.push_back(tri0);
             mesh_tab.push_back(o.n_tris);
             mesh_tab.push_back(oc.root == NO_NODE ? NO_NODE : node0 + oc.root);
             mesh_tab.push_back(leaf0);
+            mesh_tab.push_back(tb_ok ? tb0 : NO_NODE);
+            mesh_tab.push_back(0); mesh_tab.push_back(0); mesh_tab.push_back(0);
             node_tab.insert(node_tab.end(), oc.nodes.begin(), oc.nodes.end());
-            leaf_tab.insert(leaf_tab.end(), oc.leaf_ids.begin(), oc.leaf_ids.end());
+            for (u32 id : oc.leaf_ids) leaf_tab.push_back(new_of[id]);
             for (u32 t = 0; t < o.n_tris; ++t) {
-                const float *p = o.tris + (size_t)t * 9;
+                const float *p = o.tris + (size_t)order[t] * 9;
                 const H3 a = h3(p[0], p[1], p[2]), b = h3(p[3], p[4], p[5]), c = h3(p[6], p[7], p[8]);
                 const H3 e0 = hsub(b, a), e1 = hsub(c, a);
                 const float g[9] = {a.x, a.y, a.z, e0.x, e0.y, e0.z, e1.x, e1.y, e1.z};
@@ -380,23 +529,46 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
             }
             inst_tab.insert(inst_tab.end(), ir, ir + INST_WORDS);
             instx_tab.insert(instx_tab.end(), ix, ix + INSTX_WORDS);
-            // bounding sphere in world space: centre = pos, radius = largest object-space extent around pos; valid when the
-            // instance transform preserves lengths (it is a rotation unless the direction is degenerate)
-            Bound bd = {{pos.x, pos.y, pos.z}, 0.0f, o.kind != MRT_KIND_PLANE};
+            // world-space bounds: the object-space box moved to pos when the instance transform is the identity as values,
+            // else the cube around the bounding sphere (centre pos, radius = largest object-space extent), which is valid
+            // when the transform preserves lengths (it is a rotation unless the direction is degenerate)
+            Bound bd;
+            bd.ok = o.kind != MRT_KIND_PLANE;
+            for (int a = 0; a < 3; ++a) bd.mn[a] = bd.mx[a] = 0.0f;
             if (bd.ok) {
-                double rad = 0.0;
-                if (o.kind == MRT_KIND_SPHERE) rad = fabs((double)o.param[0]);
-                else if (o.kind == MRT_KIND_BOX) rad = 0.5 * sqrt((double)o.param[0] * o.param[0] + (double)o.param[1] * o.param[1] + (double)o.param[2] * o.param[2]);
-                else if (o.kind == MRT_KIND_TRIANGLE) { for (int k = 0; k < 3; ++k) { const double m = sqrt((double)o.param[3 * k] * o.param[3 * k] + (double)o.param[3 * k + 1] * o.param[3 * k + 1] + (double)o.param[3 * k + 2] * o.param[3 * k + 2]); if (!(m <= rad)) rad = m; } }
-                else { for (size_t v = 0; v < (size_t)o.n_tris * 3; ++v) { const float *q = o.tris + v * 3; const double m = sqrt((double)q[0] * q[0] + (double)q[1] * q[1] + (double)q[2] * q[2]); if (!(m <= rad)) rad = m; } }
+                double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, rad = 0.0;
+                if (o.kind == MRT_KIND_SPHERE) { rad = fabs((double)o.param[0]); for (int a = 0; a < 3; ++a) { lo[a] = -rad; hi[a] = rad; } }
+                else if (o.kind == MRT_KIND_BOX) {
+                    rad = 0.5 * sqrt((double)o.param[0] * o.param[0] + (double)o.param[1] * o.param[1] + (double)o.param[2] * o.param[2]);
+                    for (int a = 0; a < 3; ++a) { hi[a] = 0.5 * fabs((double)o.param[a]); lo[a] = -hi[a]; }
+                } else {
+                    const float *vs = o.kind == MRT_KIND_TRIANGLE ? o.param : o.tris;
+                    const size_t nv = o.kind == MRT_KIND_TRIANGLE ? 3 : (size_t)o.n_tris * 3;
+                    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+                    for (size_t v = 0; v < nv; ++v) {
+                        const float *q = vs + v * 3;
+                        const double m = sqrt((double)q[0] * q[0] + (double)q[1] * q[1] + (double)q[2] * q[2]);
+                        if (!(m <= rad)) rad = m;
+                        for (int a = 0; a < 3; ++a) { if (!(q[a] >= lo[a])) lo[a] = q[a]; if (!(q[a] <= hi[a])) hi[a] = q[a]; }
+                    }
+                    if (nv == 0) for (int a = 0; a < 3; ++a) lo[a] = hi[a] = 0.0;
+                }
                 const float *X = xf_tab.data() + (size_t)xf * XF_WORDS;
-                double M[9];
-                for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) { double acc = 0; for (int k = 0; k < 3; ++k) acc += (double)X[XF_R + a * 3 + k] * X[XF_L + k * 3 + b2]; M[a * 3 + b2] = acc; }
+                const bool ident = bits(X[XF_IDENT]) != 0;
                 bool ortho = true;
-                for (int a = 0; a < 3 && ortho; ++a) for (int b2 = 0; b2 < 3; ++b2) { double acc = 0; for (int k = 0; k < 3; ++k) acc += M[a * 3 + k] * M[b2 * 3 + k]; if (!(fabs(acc - (a == b2 ? 1.0 : 0.0)) < 1e-4)) ortho = false; }
-                const double rr = rad * 1.001 + 1e-6;
-                bd.ok = ortho && rr < 1e18 && fabs((double)pos.x) < 1e18 && fabs((double)pos.y) < 1e18 && fabs((double)pos.z) < 1e18;
-                bd.r = (float)rr;
+                if (!ident) {
+                    double M[9];
+                    for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) { double acc = 0; for (int k = 0; k < 3; ++k) acc += (double)X[XF_R + a * 3 + k] * X[XF_L + k * 3 + b2]; M[a * 3 + b2] = acc; }
+                    for (int a = 0; a < 3 && ortho; ++a) for (int b2 = 0; b2 < 3; ++b2) { double acc = 0; for (int k = 0; k < 3; ++k) acc += M[a * 3 + k] * M[b2 * 3 + k]; if (!(fabs(acc - (a == b2 ? 1.0 : 0.0)) < 1e-4)) ortho = false; }
+                    for (int a = 0; a < 3; ++a) { lo[a] = -rad; hi[a] = rad; }
+                }
+                const double pp[3] = {pos.x, pos.y, pos.z};
+                bd.ok = ortho && rad < 1e6;
+                for (int a = 0; a < 3 && bd.ok; ++a) {
+                    const double slack = 1e-3 * fmax(fabs(lo[a]), fabs(hi[a])) + 1e-6;
+                    bd.mn[a] = (float)(pp[a] + lo[a] - slack); bd.mx[a] = (float)(pp[a] + hi[a] + slack);
+                    if (!(fabs(pp[a]) < 1e6) || !(bd.mn[a] <= bd.mx[a])) bd.ok = false;     // also refuses NaN
+                }
             }
             bounds.push_back(bd);
         }
@@ -423,39 +595,9 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
         if (n_inst_total < kBvhMinInstances || elig.size() < kBvhMinInstances / 2) {
             lin_list.clear(); elig.clear();
         } else {
-            struct Build {
-                const std::vector<Bound> &bd; std::vector<float> &nodes; std::vector<u32> &ids;
-                u32 make(std::vector<u32> &v, size_t lo, size_t hi)
-                {
-                    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-                    for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) {
-                        const Bound &b = bd[v[k]];
-                        if (b.c[a] - b.r < mn[a]) mn[a] = b.c[a] - b.r;
-                        if (b.c[a] + b.r > mx[a]) mx[a] = b.c[a] + b.r;
-                    }
-                    const u32 me = (u32)(nodes.size() / BVH_WORDS);
-                    nodes.resize(nodes.size() + BVH_WORDS);
-                    u32 leaf = 0;
-                    if (hi - lo <= 2) {
-                        leaf = ((u32)(hi - lo) << 24) | (u32)ids.size();
-                        for (size_t k = lo; k < hi; ++k) ids.push_back(v[k]);
-                    } else {
-                        int ax = 0;
-                        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-                        for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) { const float c = bd[v[k]].c[a]; if (c < cmn[a]) cmn[a] = c; if (c > cmx[a]) cmx[a] = c; }
-                        for (int a = 1; a < 3; ++a) if (cmx[a] - cmn[a] > cmx[ax] - cmn[ax]) ax = a;
-                        const size_t mid = (lo + hi) / 2;
-                        std::nth_element(v.begin() + lo, v.begin() + mid, v.begin() + hi, [&](u32 x, u32 y) { return bd[x].c[ax] < bd[y].c[ax] || (bd[x].c[ax] == bd[y].c[ax] && x < y); });
-                        make(v, lo, mid);
-                        make(v, mid, hi);
-                    }
-                    float *q = nodes.data() + (size_t)me * BVH_WORDS;
-                    for (int a = 0; a < 3; ++a) { q[BVH_MIN + a] = mn[a]; q[BVH_MAX + a] = mx[a]; }
-                    q[BVH_SKIP] = fbits((u32)(nodes.size() / BVH_WORDS));      // first node after this subtree
-                    q[BVH_LEAF] = fbits(leaf);
-                    return me;
-                }
-            } build{bounds, bvh_nodes, bvh_inst};
+            std::vector<TriBox> ib(n_inst_total);
+            for (u32 i : elig) for (int a = 0; a < 3; ++a) { ib[i].mn[a] = bounds[i].mn[a]; ib[i].mx[a] = bounds[i].mx[a]; ib[i].c[a] = 0.5f * bounds[i].mn[a] + 0.5f * bounds[i].mx[a]; }
+            TbvhBuild build{ib, bvh_nodes, bvh_inst, 2u};
             build.make(elig, 0, elig.size());
             const u32 n_nodes = (u32)(bvh_nodes.size() / BVH_WORDS);
             for (u32 k = 0; k < n_nodes; ++k) { float *q = bvh_nodes.data() + (size_t)k * BVH_WORDS; if (bits(q[BVH_SKIP]) >= n_nodes) q[BVH_SKIP] = fbits(BVH_END); }
@@ -519,9 +661,16 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     P.off_mesh = B.align4(); B.w.insert(B.w.end(), mesh_tab.begin(), mesh_tab.end());
     P.off_tri = B.align4(); for (float v : tri_tab) B.f(v);
     P.off_node = B.align4(); for (float v : node_tab) B.f(v);
+    P.off_tbvh = B.align4(); for (float v : tbvh_tab) B.f(v);
+    P.off_memb = B.align4(); B.w.insert(B.w.end(), memb_tab.begin(), memb_tab.end());
+    P.off_membe = B.align4(); B.w.insert(B.w.end(), membe_tab.begin(), membe_tab.end());
+    P.off_parent = B.align4(); B.w.insert(B.w.end(), parent_tab.begin(), parent_tab.end());
+    // the octree leaf lists come last: they are not staged in LDS (only rays the TBVH cannot cull read them)
     P.off_leaf = B.align4(); B.w.insert(B.w.end(), leaf_tab.begin(), leaf_tab.end());
+    P.lds_words = P.off_leaf;
     B.align4();
     P.blob_words = (u32)B.w.size();
+    out.n_tbvh_nodes = (u32)(tbvh_tab.size() / BVH_WORDS);
     out.blob.swap(B.w);
     out.n_nodes = (u32)(node_tab.size() / NODE_WORDS);
     out.n_leaf_ids = (u32)leaf_tab.size();

@@ -16,7 +16,7 @@ struct Packed {
     u32 res_w = 0, res_h = 0;
     float gamma = 0, exp = 0;
     u32 features = 0;            // F_* bits of mrt_trace.h the scene needs
-    u32 n_tex_u8 = 0, n_tex_f32 = 0, n_nodes = 0, n_leaf_ids = 0, n_tris = 0, n_xf = 0, n_bvh_nodes = 0, n_lin = 0;
+    u32 n_tex_u8 = 0, n_tex_f32 = 0, n_nodes = 0, n_leaf_ids = 0, n_tris = 0, n_xf = 0, n_bvh_nodes = 0, n_lin = 0, n_tbvh_nodes = 0;
 };
 
 // Returns MRT_OK or an MRT_ERR_* code with a message in err.
@@ -30,6 +30,9 @@ struct OctreeFlat {
     bool empty_root = false;      // root has neither content nor children: the reference would panic
 };
 void build_octree(const float *tris, u32 n_tris, OctreeFlat &out);
+
+// Triangle BVH of one mesh (mrt_scene.h, mesh-relative skip links); order[new id] = old id.  False: mesh cannot be bounded.
+bool build_tbvh(const float *tris, u32 n_tris, std::vector<float> &nodes, std::vector<u32> &order);
 
 // Lanczos3 resampling taps of image 0.24's imageops::resize for one axis (src/sampler.rs:98).
 struct ResampleTaps {

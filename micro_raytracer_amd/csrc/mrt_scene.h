@@ -24,7 +24,7 @@ constexpr u32 XF_WORDS = 20;
 constexpr u32 MAT_WORDS = 16;
 constexpr u32 LIGHT_WORDS = 8;
 constexpr u32 TEX_WORDS = 4;
-constexpr u32 MESH_WORDS = 4;
+constexpr u32 MESH_WORDS = 8;
 constexpr u32 TRI_WORDS = 9;
 constexpr u32 NODE_WORDS = 8;
 
@@ -61,18 +61,33 @@ enum : u32 { TEX_W = 0, TEX_H = 1, TEX_OFF = 2, TEX_FMT = 3 };
 enum : u32 { TEXFMT_NONE = 0, TEXFMT_F32 = 1, TEXFMT_U8 = 2 };
 
 // MESH: [0] first triangle [1] triangle count [2] root node (0xffffffff: no octree) [3] leaf-id base
-enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3 };
+//       [4] root node of the triangle BVH (0xffffffff: none)
+enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4 };
 constexpr u32 NO_NODE = 0xffffffffu;
 
 // NODE: [0..2] 0.5*aabb  [3..5] rel_pos  [6] first child node | first leaf id  [7] count | leaf<<31
 enum : u32 { NODE_HALF = 0, NODE_REL = 3, NODE_FIRST = 6, NODE_COUNT = 7 };
 
 // BVH over renderer instances (scenes with many instances): threaded (stackless) node array in depth-first
-// order.  NODE: [0..2] bmin  [3..5] bmax  [6] skip = next node when this one is missed or is a leaf  [7] leaf word:
+// order.  NODE: [0..2] box centre  [3..5] box half size  [6] skip = next node when this one is missed or is a leaf  [7] leaf word:
 // 0 for an internal node (next = this + 1), else count << 24 | first index into the instance-id list.
 // Instances that cannot be bounded (planes, non-orthonormal transforms) are in the linear list instead.
+//
+// Triangle BVH of a mesh (TBVH, same node record, mesh-local coordinates, leaf word = count << 24 | first triangle of the
+// mesh): a pure accelerator for Renderer::intersect on meshes.  The reference answers with the first minimum / last
+// maximum of the triangle hits among the *candidates* its octree walk collects (src/rt.rs:740-770); a triangle is a
+// candidate when the ray passes the exact box tests of the root, ..., leaf chain of some octree leaf listing it.  The
+// kernel finds the triangles the ray can hit through the TBVH (conservative culling), runs the exact triangle test and
+// then decides candidacy from the membership table, so no box the ray misses and no triangle it misses is touched:
+//   MEMB  (one word per triangle, off_memb + MESH_TRI0 + id): count << 24 | first entry
+//   MEMBE (off_membe + entry): octree leaf node (relative to the mesh's root node) << 22 | slot, where slot is the
+//         position of this occurrence in the mesh's leaf-id list = its rank in the reference's candidate order
+//   PARENT (one word per octree node, off_parent + node): parent node, NO_NODE for a root
+// The mesh's triangles are stored in TBVH leaf order; the octree leaf lists hold the permuted ids (a relabelling the
+// reference cannot observe: ids only select a triangle and are compared for equality, src/rt.rs:756).
 constexpr u32 BVH_WORDS = 8;
-enum : u32 { BVH_MIN = 0, BVH_MAX = 3, BVH_SKIP = 6, BVH_LEAF = 7 };
+constexpr u32 MEMB_SLOT_BITS = 22u, MEMB_SLOT_MASK = (1u << MEMB_SLOT_BITS) - 1u;
+enum : u32 { BVH_C = 0, BVH_H = 3, BVH_SKIP = 6, BVH_LEAF = 7 };
 constexpr u32 BVH_END = 0xffffffffu;
 
 enum : u32 { KIND_SPHERE = 0, KIND_PLANE = 1, KIND_BOX = 2, KIND_TRIANGLE = 3, KIND_MESH = 4 };
@@ -100,7 +115,10 @@ struct Params {
     u32 n_lin, n_bvh_nodes;   // instance BVH: linear-list length, node count (0: every instance is scanned linearly)
     u32 off_lin, off_bvh, off_bvhinst;
     u32 off_rend, off_inst, off_instx, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
+    u32 off_tbvh, off_memb, off_membe, off_parent;
     u32 blob_words;
+    u32 lds_words;            // words a workgroup stages in LDS: everything before the octree leaf lists when every mesh has a
+                              // triangle BVH (the lists are then only read, from global memory, by rays that cannot be culled)
     u32 tiles_x, tiles_y;    // 8x8-pixel wave tiles per workgroup in x and y
     u32 count_segments;
     // device pointers

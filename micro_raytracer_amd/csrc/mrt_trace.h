@@ -31,6 +31,11 @@ enum : u32 {
 #ifndef MRT_PROBE
 #define MRT_PROBE(phase)
 #endif
+// Work counters, likewise only defined by tests/emu/probe.cpp.
+#ifndef MRT_COUNT
+#define MRT_COUNT(counter)
+#endif
+enum : u32 { CT_TRACE = 0, CT_LIN_TEST, CT_BVH_NODE, CT_BVH_TEST, CT_MESH_CALL, CT_MESH_ROOT_HIT, CT_TBVH_NODE, CT_TBVH_TRI, CT_TBVH_TRI_HIT, CT_MEMB_BOX, CT_COUNT };
 enum : u32 { PH_ITER = 0, PH_REGEN, PH_SPHERE_MATH, PH_PLANE_HIT, PH_SHADE, PH_NORMAL_NONPLANE, PH_SCATTER1, PH_SCATTER2, PH_REFRACT, PH_EMIT_END, PH_LIGHTS, PH_COUNT };
 
 constexpr float kE = 0.0001f;                 // src/rt.rs:7
@@ -198,6 +203,7 @@ struct Scn {
     const float *F;      // the packed scene (LDS): per-lane (divergent) lookups
     const float *U;      // the same blob for wave-uniform reads of the traversal loop: LDS, or global memory
                          // read through the scalar cache into SGPRs (MRT_UNIFORM_SMEM)
+    const float *G;      // the whole blob in global memory (the octree leaf lists are not staged when every mesh has a TBVH)
     const Params *P;
 };
 
@@ -249,23 +255,149 @@ MRT_HD RayPre ray_pre(V3 o, V3 d)
     return r;
 }
 
+// ---- conservative ray / box culling shared by the instance BVH and the triangle BVHs (never decides a result) ----
+// The slab test runs on the box grown by a margin mg: t = (c - o) * inv -+ (h + mg) * |inv| per axis, with the
+// reciprocal direction clamped to +-1e30 (a zero component then reads as "parallel": no constraint inside the slab,
+// a sure miss outside) -- coordinates on this route are bounded by 1e6, so nothing overflows and no NaN can arise.
+struct CullRay {
+    V3 o, inv, ainv;
+};
+MRT_HD float clamp_inv(float d) { return fmin_(fmax_(rcp_fast(d), -1e30f), 1e30f); }
+MRT_HD CullRay cull_ray(V3 o, V3 d)
+{
+    CullRay c;
+    c.o = o;
+    c.inv = v3(clamp_inv(d.x), clamp_inv(d.y), clamp_inv(d.z));
+    c.ainv = v3(fabs_(c.inv.x), fabs_(c.inv.y), fabs_(c.inv.z));
+    return c;
+}
+MRT_HD bool cull_ok(V3 o, float dd)     // finite origin within the bounded range, unit-length finite direction
+{
+    return nzfin(dd) && dd > 0.98f && dd < 1.02f && fabs_(o.x) < 1e6f && fabs_(o.y) < 1e6f && fabs_(o.z) < 1e6f;
+}
+// Margin: 4e-3 x (largest coordinate distance from the origin to the far side of the box) -- more than a thousand times the
+// rounding error of the exact tests at that distance -- plus 1e-5 x the coordinate magnitudes involved (rounding of
+// positions themselves: T + pos, c - o), DESIGN.md §7.
+#ifndef MRT_MG
+#define MRT_MG 4e-3f
+#endif
+MRT_HD float cull_margin(V3 r, V3 h, float big)
+{
+    const float ext = fmax_(fmax_(fabs_(r.x) + h.x, fabs_(r.y) + h.y), fabs_(r.z) + h.z);
+    return fma_fast(MRT_MG, ext, fma_fast(1e-5f, big, 1e-6f));
+}
+MRT_HD bool cull_slab(const CullRay &R, V3 r, V3 h, float mg, float &tn)
+{
+    const V3 p = hadam(r, R.inv);
+    const V3 q = hadam(v3(h.x + mg, h.y + mg, h.z + mg), R.ainv);
+    tn = fmax_(fmax_(p.x - q.x, p.y - q.y), p.z - q.z);
+    const float tf = fmin_(fmin_(p.x + q.x, p.y + q.y), p.z + q.z);
+    return !(tn > tf || tf < 0.0f);
+}
+
 // Mesh arm of Renderer::intersect with the octree walk of intersect_bvh, src/rt.rs:707-723, 740-772.
 // The candidate list is consumed in the reference's order (leaf lists of hit leaves, concatenated,
 // consecutive duplicates dropped) without being materialised.
 template <bool ANY>
-MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
+MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
 {
     const float *F = S.F;
-    const float *M = F + S.P->off_mesh + mesh * MESH_WORDS;
+    const Params &P = *S.P;
+    const float *M = F + P.off_mesh + mesh * MESH_WORDS;
     const u32 tri0 = ldu(M, MESH_TRI0), ntri = ldu(M, MESH_NTRI), root = ldu(M, MESH_ROOT), leaf0 = ldu(M, MESH_LEAF0);
+    const u32 tb = ldu(M, MESH_TBVH);
     bool any = false;
     i32 k0 = 0, k1 = 0;
-    u32 last_id = 0xffffffffu;
+    MRT_COUNT(CT_MESH_CALL);
 
+    // ---- triangle BVH route (mrt_scene.h): the triangles the ray hits, then their candidacy in the reference's octree walk ----
+    const V3 ol = sub(ro, pos);
+    if (tb != NO_NODE && cull_ok(ol, dd) && fabs_(pos.x) < 1e6f && fabs_(pos.y) < 1e6f && fabs_(pos.z) < 1e6f) {
+        const float *N0 = F + P.off_node;
+        float a0, a1;
+        // a ray that misses the octree root has no candidates at all, src/rt.rs:745
+        if (!box_isect(ld3(N0, root * NODE_WORDS + NODE_HALF), ro, m, add(pos, ld3(N0, root * NODE_WORDS + NODE_REL)), a0, a1)) return false;
+        MRT_COUNT(CT_MESH_ROOT_HIT);
+        const float *B0 = F + P.off_tbvh;
+        // one culling margin per ray, from the mesh bounds (the TBVH root)
+        const CullRay R = cull_ray(ol, rd);
+        V3 oinv, qm;
+        {
+            const F4 ra = ld4(B0, tb * BVH_WORDS), rb = ld4(B0, tb * BVH_WORDS + 4);
+            const V3 c = v3(ra.x, ra.y, ra.z), hh = v3(ra.w, rb.x, rb.y);
+            const float big = fmax_(fmax_(fabs_(pos.x), fabs_(pos.y)), fabs_(pos.z)) + fmax_(fmax_(fabs_(c.x) + hh.x, fabs_(c.y) + hh.y), fabs_(c.z) + hh.z)
+                              + fmax_(fmax_(fabs_(ol.x), fabs_(ol.y)), fabs_(ol.z));
+            const float mg = cull_margin(sub(c, ol), hh, big);
+            oinv = hadam(ol, R.inv);
+            qm = muls(R.ainv, mg);
+        }
+        u32 s0 = 0, s1 = 0;
+        u32 node = tb;
+        for (;;) {
+            u32 leaf = 0u, skip = BVH_END;
+            while (node != BVH_END) {
+                const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
+                MRT_COUNT(CT_TBVH_NODE);
+                skip = f2u(nb.z);
+                leaf = f2u(nb.w);
+                // t = c * inv - o * inv -+ (h * |inv| + mg * |inv|)
+                const float px = fma_fast(na.x, R.inv.x, -oinv.x), py = fma_fast(na.y, R.inv.y, -oinv.y), pz = fma_fast(na.z, R.inv.z, -oinv.z);
+                const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);
+                const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
+                const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
+                if (tn > tf || tf < 0.0f) { node = skip; continue; }
+                if (leaf != 0u) break;
+                node = node + 1u;
+            }
+            if (node == BVH_END) break;
+            const u32 cnt = leaf >> 24, first = leaf & 0xffffffu;
+            for (u32 j = 0; j < cnt; ++j) {
+                const u32 id = first + j;
+                const float *T = F + P.off_tri + (tri0 + id) * TRI_WORDS;
+                float t;
+                MRT_COUNT(CT_TBVH_TRI);
+                if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t)) continue;
+                MRT_COUNT(CT_TBVH_TRI_HIT);
+                // candidate iff some octree leaf listing the triangle is reached: every box from that leaf up to the root hit
+                const u32 head = ldu(F, P.off_memb + tri0 + id);
+                const u32 e0 = head & 0xffffffu, ne = head >> 24;
+                u32 sl = 0xffffffffu, sh = 0u;
+                bool cand = false;
+                for (u32 e = 0; e < ne; ++e) {
+                    const u32 w = ldu(F, P.off_membe + e0 + e);
+                    u32 n = root + (w >> MEMB_SLOT_BITS);
+                    bool reached = true;
+                    while (n != root) {
+                        MRT_COUNT(CT_MEMB_BOX);
+                        if (!box_isect(ld3(N0, n * NODE_WORDS + NODE_HALF), ro, m, add(pos, ld3(N0, n * NODE_WORDS + NODE_REL)), a0, a1)) { reached = false; break; }
+                        n = ldu(F, P.off_parent + n);
+                    }
+                    if (!reached) continue;
+                    if (ANY) return true;
+                    const u32 slot = w & MEMB_SLOT_MASK;    // entries are in slot order
+                    if (!cand) sl = slot;
+                    sh = slot;
+                    cand = true;
+                }
+                if (!cand) continue;
+                const i32 k = total_key(t);
+                if (!any) { any = true; t0 = t1 = t; i0 = i1 = (i32)id; k0 = k1 = k; s0 = sl; s1 = sh; continue; }
+                if (k < k0 || (k == k0 && sl < s0)) { k0 = k; s0 = sl; t0 = t; i0 = (i32)id; }      // min_by: first minimum, src/rt.rs:764
+                if (k > k1 || (k == k1 && sh > s1)) { k1 = k; s1 = sh; t1 = t; i1 = (i32)id; }      // max_by: last maximum, src/rt.rs:765
+            }
+            node = skip;
+        }
+        return any;
+    }
+
+    // ---- the reference's own walk (rays the TBVH must not cull: non-finite or non-unit; meshes without a TBVH) ----
+    // The candidate list is consumed in the reference's order (leaf lists of hit leaves, concatenated,
+    // consecutive duplicates dropped) without being materialised.  The leaf lists are read from global memory.
+    u32 last_id = 0xffffffffu;
     auto test = [&](u32 id) {
         if (id == last_id) return;          // Vec::dedup (src/rt.rs:756)
         last_id = id;
-        const float *T = F + S.P->off_tri + (tri0 + id) * TRI_WORDS;
+        const float *T = F + P.off_tri + (tri0 + id) * TRI_WORDS;
         float t;
         if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t)) return;
         const i32 k = total_key(t);
@@ -282,24 +414,21 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, float
     u32 cur[4], end[4];
     int sp = 0;
     cur[0] = root; end[0] = root + 1;
-    bool root_hit = false;
     while (sp >= 0) {
         if (cur[sp] == end[sp]) { --sp; continue; }
         const u32 node = cur[sp]++;
-        const float *N = F + S.P->off_node + node * NODE_WORDS;
+        const float *N = F + P.off_node + node * NODE_WORDS;
         float a0, a1;
         if (!box_isect(ld3(N, NODE_HALF), ro, m, add(pos, ld3(N, NODE_REL)), a0, a1)) continue;
-        if (node == root) root_hit = true;
         const u32 first = ldu(N, NODE_FIRST), cnt = ldu(N, NODE_COUNT);
         if (cnt & 0x80000000u) {
             const u32 n = cnt & 0x7fffffffu;
-            for (u32 i = 0; i < n; ++i) { test(ldu(F, S.P->off_leaf + leaf0 + first + i)); if (ANY && any) return true; }
+            for (u32 i = 0; i < n; ++i) { test(ldu(S.G, P.off_leaf + leaf0 + first + i)); if (ANY && any) return true; }
         } else if (sp < 3) {
             ++sp;
             cur[sp] = first; end[sp] = first + cnt;
         }
     }
-    (void)root_hit;
     return any;
 }
 
@@ -335,7 +464,7 @@ MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia,
             t1 = t0;
             return h;
         }
-        if ((FEAT & F_BOX) && kind == KIND_MESH) return mesh_isect<ANY>(S, ldu(R, REND_GEO), ro, rd, m, pos, t0, i0, t1, i1);
+        if ((FEAT & F_BOX) && kind == KIND_MESH) return mesh_isect<ANY>(S, ldu(R, REND_GEO), ro, rd, dd, m, pos, t0, i0, t1, i1);
     }
     return false;
 }
@@ -353,8 +482,10 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     best.rend = -1; best.inst = 0; best.t0 = 0.0f; best.t1 = 0.0f; best.i0 = -1; best.i1 = -1;
     const float *I = F + P.off_inst;
 
+    MRT_COUNT(CT_TRACE);
     auto consider = [&](u32 i, const F4 &ia, const F4 &ib) -> bool {
         float t0, t1;
+        MRT_COUNT(CT_LIN_TEST);
         i32 i0, i1;
         if (!isect_instance<ANY, FEAT>(S, ray, i, ia, ib, t0, t1, i0, i1)) return false;
         if (ANY) return true;
@@ -390,9 +521,9 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         // misses its box grown by 4e-3 x (largest coordinate distance from the origin to the far side of the box): more
         // than a thousand times the rounding error of the exact tests at that distance.  Rays that are
         // not finite or not unit length are not culled at all.
-        const V3 o = ray.o, d = ray.d;
-        const bool cull = nzfin(ray.dd) && ray.dd > 0.98f && ray.dd < 1.02f && fabs_(o.x) < 1e18f && fabs_(o.y) < 1e18f && fabs_(o.z) < 1e18f;
-        const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const bool cull = cull_ok(ray.o, ray.dd);
+        const CullRay R = cull_ray(ray.o, ray.d);
+        const float obig = fmax_(fmax_(fabs_(ray.o.x), fabs_(ray.o.y)), fabs_(ray.o.z));
         const float *N0 = F + P.off_bvh;
         u32 node = P.n_bvh_nodes ? 0u : BVH_END;
         // "while-while": every lane first walks boxes until it stands on a leaf (cheap iterations, all lanes busy), then
@@ -401,20 +532,16 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
             u32 leaf = 0u, skip = BVH_END;
             while (node != BVH_END) {
                 const F4 na = ld4(N0, node * BVH_WORDS), nb = ld4(N0, node * BVH_WORDS + 4);
+                MRT_COUNT(CT_BVH_NODE);
                 skip = f2u(nb.z);
                 leaf = f2u(nb.w);
                 bool hit_node = true;
                 if (cull) {
-                    const V3 bmin = v3(na.x, na.y, na.z), bmax = v3(na.w, nb.x, nb.y);
-                    const V3 c = muls(add(bmin, bmax), 0.5f), hh = muls(sub(bmax, bmin), 0.5f);
-                    const float ext = fmax_(fmax_(fabs_(o.x - c.x) + hh.x, fabs_(o.y - c.y) + hh.y), fabs_(o.z - c.z) + hh.z);
-                    const float mg = 4e-3f * ext + 1e-6f;
-                    const float ax = (bmin.x - mg - o.x) * inv.x, bx = (bmax.x + mg - o.x) * inv.x;
-                    const float ay = (bmin.y - mg - o.y) * inv.y, by = (bmax.y + mg - o.y) * inv.y;
-                    const float az = (bmin.z - mg - o.z) * inv.z, bz = (bmax.z + mg - o.z) * inv.z;
-                    const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
-                    const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
-                    if (tn > tf || tf < 0.0f) hit_node = false;
+                    const V3 c = v3(na.x, na.y, na.z), hh = v3(na.w, nb.x, nb.y);
+                    const V3 r = sub(c, R.o);
+                    const float mg = cull_margin(r, hh, obig + obig);
+                    float tn;
+                    hit_node = cull_slab(R, r, hh, mg, tn);
                     // nothing in a node whose near side lies beyond the current closest hit can win
                     if (!ANY && best.rend >= 0 && best.t0 >= 0.0f && tn > best.t0 + 1e-3f * best.t0 + mg) hit_node = false;
                 }

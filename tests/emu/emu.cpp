@@ -56,7 +56,7 @@ int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, ui
     if (row1 > pk.nh) row1 = pk.nh;
     Scn S;
     S.F = reinterpret_cast<const float *>(pk.blob.data());
-    S.U = S.F;
+    S.U = S.F; S.G = S.F;
     S.P = &P;
     std::atomic<uint32_t> next(row0);
     std::atomic<uint64_t> segs(0);
@@ -140,6 +140,48 @@ void emu_math(int op, const float *a, const float *b, float *out, size_t n)
         }
         out[i] = r;
     }
+}
+
+// Mesh arm of Renderer::intersect for n rays against renderer 0 (a mesh), through the TBVH route and through the reference's
+// octree walk (forced by dd = NaN, which only steers the route).  out[i*10..]: hit, t0 bits, i0, t1 bits, i1 for each route.
+// Returns the number of rays on which the routes differ (ANY queries included), or < 0.
+int emu_mesh_probe(const mrt_render_desc *d, uint32_t n, const float *orig, const float *dir, uint32_t *out, uint32_t *stats /*[2]*/)
+{
+    Packed pk;
+    const int rc = pack_scene(d, pk, g_err);
+    if (rc) return rc;
+    Params P = pk.P;
+    Scn S;
+    S.F = reinterpret_cast<const float *>(pk.blob.data());
+    S.U = S.F; S.G = S.F; S.P = &P;
+    if (P.n_inst == 0) return -100;
+    int bad = 0;
+    uint32_t hits = 0, with_tbvh = 0;
+    const float *M = S.F + P.off_mesh;
+    with_tbvh = ldu(M, MESH_TBVH) != NO_NODE;
+    for (uint32_t i = 0; i < n; ++i) {
+        const V3 o = v3(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]), dr = v3(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
+        const RayPre ray = ray_pre<F_ALL>(o, dr);
+        uint32_t r[2][5];
+        bool anyq[2];
+        for (int route = 0; route < 2; ++route) {
+            const float *I = S.F + P.off_inst;
+            const F4 ia = ld4(I, 0);
+            const V3 pos = v3(ia.x, ia.y, ia.z);
+            const float dd = route == 0 ? ray.dd : __builtin_nanf("");
+            float t0 = 0, t1 = 0; i32 i0 = -1, i1 = -1;
+            const V3 ro = add(pos, sub(ray.o, pos));
+            const bool h = mesh_isect<false>(S, 0, ro, ray.d, dd, ray.m, pos, t0, i0, t1, i1);
+            float u0 = 0, u1 = 0; i32 j0 = -1, j1 = -1;
+            anyq[route] = mesh_isect<true>(S, 0, ro, ray.d, dd, ray.m, pos, u0, j0, u1, j1);
+            r[route][0] = h; r[route][1] = h ? f2u(t0) : 0; r[route][2] = h ? (u32)i0 : 0; r[route][3] = h ? f2u(t1) : 0; r[route][4] = h ? (u32)i1 : 0;
+        }
+        if (r[0][0]) ++hits;
+        if (memcmp(r[0], r[1], sizeof r[0]) != 0 || anyq[0] != anyq[1] || anyq[0] != (bool)r[0][0]) ++bad;
+        if (out) { memcpy(out + (size_t)i * 10, r[0], sizeof r[0]); memcpy(out + (size_t)i * 10 + 5, r[1], sizeof r[1]); }
+    }
+    if (stats) { stats[0] = hits; stats[1] = with_tbvh; }
+    return bad;
 }
 
 // leaves of mesh renderer `mesh_index`-th mesh in traversal order, to compare the packer's octree with the oracle's

@@ -9,7 +9,11 @@
 #include <vector>
 
 static thread_local std::vector<uint16_t> *g_rec = nullptr;   // one bitmask per iteration
-#define MRT_PROBE(phase) do { if (g_rec) { if ((phase) == 0) g_rec->push_back(1); else g_rec->back() |= (uint16_t)(1u << (phase)); } } while (0)
+#define MRT_PROBE(phase) do { if (g_work && (phase) == 0) g_work->push_back(0); if (g_rec) { if ((phase) == 0) g_rec->push_back(1); else g_rec->back() |= (uint16_t)(1u << (phase)); } } while (0)
+
+static thread_local uint64_t g_cnt[32];
+static thread_local std::vector<uint32_t> *g_work = nullptr;   // per loop iteration: BVH / TBVH nodes + 3 x exact tests of the lane
+#define MRT_COUNT(counter) do { ++g_cnt[counter]; if (g_work && !g_work->empty()) { if ((counter) == 2 || (counter) == 6) g_work->back() += 1; else if ((counter) == 1 || (counter) == 7) g_work->back() += 3; } } while (0)
 
 #include "../../micro_raytracer_amd/csrc/mrt_pack.h"
 #include "../../micro_raytracer_amd/csrc/mrt_trace.h"
@@ -24,7 +28,7 @@ extern "C" int probe_divergence(const mrt_render_desc *d, uint64_t seed, uint32_
     P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
     P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.n_samples = n_samples; P.sample_base = 0; P.k_split = 1;
     std::vector<float> frame((size_t)pk.nw * pk.nh * 3, 0.0f); P.accum = frame.data();
-    Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.P = &P;
+    Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.G = S.F; S.P = &P;
     for (u32 p = 0; p < PH_COUNT; ++p) { active[p] = 0; executed[p] = 0; }
     for (uint32_t ty = tile_y0; ty < tile_y0 + tiles_y; ++ty)
         for (uint32_t tx = tile_x0; tx < tile_x0 + tiles_x; ++tx) {
@@ -48,4 +52,66 @@ extern "C" int probe_divergence(const mrt_render_desc *d, uint64_t seed, uint32_
                 }
         }
     return 0;
+}
+
+// work counters (CT_* of mrt_trace.h) summed over every pixel of the frame, n_samples each
+extern "C" int probe_counts(const mrt_render_desc *d, uint64_t seed, uint32_t n_samples, uint64_t *counts /*[CT_COUNT]*/, uint64_t *segments)
+{
+    Packed pk; std::string err;
+    if (pack_scene(d, pk, err)) return -1;
+    Params P = pk.P;
+    P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
+    P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.n_samples = n_samples; P.sample_base = 0; P.k_split = 1;
+    std::vector<float> frame((size_t)pk.nw * pk.nh * 3, 0.0f); P.accum = frame.data();
+    Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.G = S.F; S.P = &P;
+    memset(g_cnt, 0, sizeof g_cnt);
+    uint64_t seg = 0;
+    for (uint32_t y = 0; y < pk.nh; ++y)
+        for (uint32_t x = 0; x < pk.nw; ++x) {
+            u32 sg = 0; RegStash st;
+            LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u;
+            if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg);
+            seg += sg;
+        }
+    for (u32 c = 0; c < CT_COUNT; ++c) counts[c] = g_cnt[c];
+    if (segments) *segments = seg;
+    return (int)CT_COUNT;
+}
+
+// SIMT efficiency of the traversal work inside one loop iteration: per 8x8 wave tile and iteration, the wavefront pays
+// max over lanes of the lane's work units (nodes + 3 x exact tests); returns sum(mean over 64 lanes) / sum(max).
+extern "C" double probe_traversal_efficiency(const mrt_render_desc *d, uint64_t seed, uint32_t n_samples, uint32_t tile_x0, uint32_t tile_y0,
+                                             uint32_t tiles_x, uint32_t tiles_y, double *mean_work, double *max_work)
+{
+    Packed pk; std::string err;
+    if (pack_scene(d, pk, err)) return -1;
+    Params P = pk.P;
+    P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
+    P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.n_samples = n_samples; P.sample_base = 0; P.k_split = 1;
+    std::vector<float> frame((size_t)pk.nw * pk.nh * 3, 0.0f); P.accum = frame.data();
+    Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.G = S.F; S.P = &P;
+    double sum_mean = 0, sum_max = 0;
+    for (uint32_t ty = tile_y0; ty < tile_y0 + tiles_y; ++ty)
+        for (uint32_t tx = tile_x0; tx < tile_x0 + tiles_x; ++tx) {
+            std::vector<std::vector<uint32_t>> w(64);
+            size_t max_it = 0;
+            for (int l = 0; l < 64; ++l) {
+                const uint32_t x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
+                if (x >= pk.nw || y >= pk.nh) continue;
+                g_work = &w[l];
+                u32 sg = 0; RegStash st;
+                LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u;
+                if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg);
+                g_work = nullptr;
+                if (w[l].size() > max_it) max_it = w[l].size();
+            }
+            for (size_t k = 0; k < max_it; ++k) {
+                uint32_t mx = 0; double sm = 0;
+                for (int l = 0; l < 64; ++l) if (k < w[l].size()) { sm += w[l][k]; if (w[l][k] > mx) mx = w[l][k]; }
+                sum_mean += sm / 64.0; sum_max += mx;
+            }
+        }
+    if (mean_work) *mean_work = sum_mean;
+    if (max_work) *max_work = sum_max;
+    return sum_max > 0 ? sum_mean / sum_max : 1.0;
 }

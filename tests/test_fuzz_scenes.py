@@ -50,6 +50,24 @@ def random_scene(seed):
     }
 
 
+def crowd_scene(seed):
+    """random_scene with 4-40 extra instances per non-plane renderer: enough to switch on the instance BVH."""
+    d = random_scene(seed)
+    rng = np.random.default_rng(seed + 77777)
+    for o in d["scene"]["renderer"]:
+        if o["type"] == "plane":
+            continue
+        base = o.pop("inst", None) or [[o.pop("pos", [0, 0, 0]), o.pop("dir", [0, 0, -1, 0])]]
+        o.pop("pos", None); o.pop("dir", None)
+        inst = list(base)
+        for _ in range(int(rng.integers(4, 40))):
+            q = [float(x) for x in np.r_[rng.uniform(-0.9, 0.9), rng.normal(size=3)]] if rng.random() < 0.3 else [0, 0, -1, 0]
+            inst.append([[float(x) for x in rng.uniform(-3, 3, 3)], q])
+        o["inst"] = inst
+    d["frame"]["res"] = [int(rng.integers(6, 20)), int(rng.integers(6, 14))]
+    return d
+
+
 def _check(got, ref, spp):
     assert (np.isnan(got) == np.isnan(ref)).all()
     fin = np.isfinite(ref)
@@ -58,9 +76,9 @@ def _check(got, ref, spp):
         assert np.abs(got[fin] - ref[fin]).max() / spp <= 1e-4 * scale
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", list(range(40)) + [1000 + k for k in range(8)])
 def test_fuzz_kernel_headers_on_x86(seed, oracle_mod, emu_mod):
-    render, h = make_holder(random_scene(seed))
+    render, h = make_holder(crowd_scene(seed - 1000) if seed >= 1000 else random_scene(seed))
     spp = render.rt.sample
     o = oracle_mod.Oracle(h, seed=seed)
     o.execute(spp)
@@ -73,10 +91,10 @@ def test_fuzz_kernel_headers_on_x86(seed, oracle_mod, emu_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(0, 40, 3))
+@pytest.mark.parametrize("seed", list(range(0, 40, 3)) + [1000, 1001, 1002, 1004])
 def test_fuzz_gpu(seed, oracle_mod):
     from micro_raytracer_amd import Sampler
-    render, h = make_holder(random_scene(seed))
+    render, h = make_holder(crowd_scene(seed - 1000) if seed >= 1000 else random_scene(seed))
     spp = render.rt.sample
     o = oracle_mod.Oracle(h, seed=seed)
     o.execute(spp)
