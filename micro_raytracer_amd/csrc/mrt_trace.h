@@ -35,7 +35,7 @@ enum : u32 {
 #ifndef MRT_COUNT
 #define MRT_COUNT(counter)
 #endif
-enum : u32 { CT_TRACE = 0, CT_LIN_TEST, CT_BVH_NODE, CT_BVH_TEST, CT_MESH_CALL, CT_MESH_ROOT_HIT, CT_TBVH_NODE, CT_TBVH_TRI, CT_TBVH_TRI_HIT, CT_MEMB_BOX, CT_COUNT };
+enum : u32 { CT_TRACE = 0, CT_LIN_TEST, CT_BVH_NODE, CT_BVH_TEST, CT_MESH_CALL, CT_MESH_ROOT_HIT, CT_TBVH_NODE, CT_TBVH_TRI, CT_TBVH_TRI_HIT, CT_MEMB_BOX, CT_TRACE_ANY, CT_COUNT };
 enum : u32 { PH_ITER = 0, PH_REGEN, PH_SPHERE_MATH, PH_PLANE_HIT, PH_SHADE, PH_NORMAL_NONPLANE, PH_SCATTER1, PH_SCATTER2, PH_REFRACT, PH_EMIT_END, PH_LIGHTS, PH_COUNT };
 
 constexpr float kE = 0.0001f;                 // src/rt.rs:7
@@ -482,7 +482,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     best.rend = -1; best.inst = 0; best.t0 = 0.0f; best.t1 = 0.0f; best.i0 = -1; best.i1 = -1;
     const float *I = F + P.off_inst;
 
-    MRT_COUNT(CT_TRACE);
+    if (ANY) { MRT_COUNT(CT_TRACE_ANY); } else { MRT_COUNT(CT_TRACE); }
     auto consider = [&](u32 i, const F4 &ia, const F4 &ib) -> bool {
         float t0, t1;
         MRT_COUNT(CT_LIN_TEST);

@@ -47,16 +47,38 @@ def gather_frame(local, nh: int, nw: int, shard_rows: int = DEFAULT_SHARD_ROWS, 
     # through host staging copies.
     staged = local.is_cuda and dist.get_backend(group) != "nccl"
     send = local.cpu() if staged else local
-    if rank == dst:
+    parts = None
+    try:
+        if rank == dst:
+            parts = [torch.empty_like(send) for _ in range(world)]
+            dist.gather(send, gather_list=parts, dst=dst, group=group)
+        else:
+            dist.gather(send, gather_list=None, dst=dst, group=group)
+    except (NotImplementedError, RuntimeError) as e:
+        # a backend build without gather raises before anything is sent, on every rank alike: all-gather instead
+        if "gather" not in str(e).lower() and not isinstance(e, NotImplementedError):
+            raise
         parts = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, gather_list=parts, dst=dst, group=group)
-        frame = out if out is not None else torch.empty((nh, nw, 3), dtype=local.dtype, device=local.device)
-        for r, part in enumerate(parts):
-            rows = torch.from_numpy(shard_row_index(nh, r, world, shard_rows)).to(local.device)
-            frame.index_copy_(0, rows, part[: rows.numel()].to(local.device))
-        return frame
-    dist.gather(send, gather_list=None, dst=dst, group=group)
-    return None
+        dist.all_gather(parts, send, group=group)
+    if rank != dst:
+        return None
+    frame = out if out is not None else torch.empty((nh, nw, 3), dtype=local.dtype, device=local.device)
+    for r, part in enumerate(parts):
+        rows = _rows_on(local.device, nh, r, world, shard_rows)
+        frame.index_copy_(0, rows, part[: rows.numel()].to(local.device))
+    return frame
+
+
+_ROWS_CACHE = {}
+
+
+def _rows_on(device, nh, rank, world, shard_rows):
+    """shard_row_index as a tensor on `device`, cached (the gather runs once per batch of samples)."""
+    import torch
+    key = (str(device), nh, rank, world, shard_rows)
+    if key not in _ROWS_CACHE:
+        _ROWS_CACHE[key] = torch.from_numpy(shard_row_index(nh, rank, world, shard_rows)).to(device)
+    return _ROWS_CACHE[key]
 
 
 class ShardedSampler:
