@@ -217,7 +217,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     //   64 threads instead when this context owns few tiles (small frames, one shard of a multi-GPU frame);
     //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves;
     //   scenes that do not fit the LDS are read through L2.
-    c->scene_in_lds = blob_bytes + 1024 <= kLdsLimit;
+    c->scene_in_lds = blob_bytes + 1024 <= kLdsLimit && !getenv("MRT_SCENE_IN_L2");      // env: experiments only
     const unsigned long long wave_tiles = (unsigned long long)((nw + 7) / 8) * ((c->local_rows + 7) / 8);
     const char *force = getenv("MRT_BLOCK_THREADS");      // experiments only
     u32 want = 256u;

@@ -275,16 +275,21 @@ MRT_HD bool cull_ok(V3 o, float dd)     // finite origin within the bounded rang
 {
     return nzfin(dd) && dd > 0.98f && dd < 1.02f && fabs_(o.x) < 1e6f && fabs_(o.y) < 1e6f && fabs_(o.z) < 1e6f;
 }
-// Margin: 4e-3 x (largest coordinate distance from the origin to the far side of the box) -- more than a thousand times the
-// rounding error of the exact tests at that distance -- plus 1e-5 x the coordinate magnitudes involved (rounding of
-// positions themselves: T + pos, c - o), DESIGN.md §7.
-#ifndef MRT_MG
-#define MRT_MG 4e-3f
+// Margin = k x (largest coordinate distance from the origin to the far side of the box) + 1e-5 x the coordinate
+// magnitudes involved (rounding of positions themselves: T + pos, c - o) + 1e-6, DESIGN.md §7.
+//   instance BVH, k = 4e-3: the sphere test's discriminant cancels (b*b - 4ac), so a far, small sphere can answer "hit"
+//     for a ray passing outside it by ~8 eps |oo|^2 / r; 4e-3 covers spheres down to 1/8000 of their distance.
+//   triangle BVH, k = 5e-4: the Moller-Trumbore test has no such cancellation -- a ray it accepts passes within
+//     ~10 eps |tv| = 6e-7 x distance of the triangle at any incidence (near-parallel rays are rejected by |det| < E
+//     before they can amplify) -- so 5e-4 is still ~800 x the bound.
+#ifndef MRT_MARGIN_SCALE            // tests/mesh_probe.py builds with 0 to show that the probe sees an unsafe margin
+#define MRT_MARGIN_SCALE 1.0f
 #endif
-MRT_HD float cull_margin(V3 r, V3 h, float big)
+constexpr float kMarginInst = 4e-3f * MRT_MARGIN_SCALE, kMarginTri = 5e-4f * MRT_MARGIN_SCALE;
+MRT_HD float cull_margin(float k, V3 r, V3 h, float big)
 {
     const float ext = fmax_(fmax_(fabs_(r.x) + h.x, fabs_(r.y) + h.y), fabs_(r.z) + h.z);
-    return fma_fast(MRT_MG, ext, fma_fast(1e-5f, big, 1e-6f));
+    return fma_fast(k, ext, fma_fast(1e-5f * MRT_MARGIN_SCALE, big, 1e-6f * MRT_MARGIN_SCALE));
 }
 MRT_HD bool cull_slab(const CullRay &R, V3 r, V3 h, float mg, float &tn)
 {
@@ -327,7 +332,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             const V3 c = v3(ra.x, ra.y, ra.z), hh = v3(ra.w, rb.x, rb.y);
             const float big = fmax_(fmax_(fabs_(pos.x), fabs_(pos.y)), fabs_(pos.z)) + fmax_(fmax_(fabs_(c.x) + hh.x, fabs_(c.y) + hh.y), fabs_(c.z) + hh.z)
                               + fmax_(fmax_(fabs_(ol.x), fabs_(ol.y)), fabs_(ol.z));
-            const float mg = cull_margin(sub(c, ol), hh, big);
+            const float mg = cull_margin(kMarginTri, sub(c, ol), hh, big);
             oinv = hadam(ol, R.inv);
             qm = muls(R.ainv, mg);
         }
@@ -539,7 +544,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
                 if (cull) {
                     const V3 c = v3(na.x, na.y, na.z), hh = v3(na.w, nb.x, nb.y);
                     const V3 r = sub(c, R.o);
-                    const float mg = cull_margin(r, hh, obig + obig);
+                    const float mg = cull_margin(kMarginInst, r, hh, obig + obig);
                     float tn;
                     hit_node = cull_slab(R, r, hh, mg, tn);
                     // nothing in a node whose near side lies beyond the current closest hit can win

@@ -35,3 +35,7 @@ if __name__ == "__main__":
     run("mesh 480x270x4", scenes.mesh_scene(res=(480, 270), sample=4), 4)
     run("minecraft 480x270 ssaa2 x4", scenes.minecraft_like(res=(480, 270), ssaa=2, sample=4), 4)
     run("instance 640x360x4", scenes.instance_grid(res=(640, 360), sample=4), 4)
+    big = scenes.mesh_scene(res=(960, 540), sample=8)
+    big["scene"]["renderer"][0]["mesh"] = [[[float(c) for c in v] for v in t] for t in scenes.icosphere(5, 0.45, (1.3, 1.0, 1.1))]
+    run("mesh 20480 tris 960x540x8 (scene in L2)", big, 8)
+    run("instance 1000 spheres 1920x1080x8", scenes.instance_grid(res=(1920, 1080), sample=8), 8)

@@ -58,6 +58,18 @@ def rays_for(rng, tris, n):
     # some axis rays start exactly on cell boundaries
     snap = axis & (rng.random(n) < 0.5)
     o = np.where(snap[:, None], np.round(o / (ext / 4)) * (ext / 4), o)
+    # grazing rays: start on the line through a triangle edge, far outside, run along the edge with a tiny tilt
+    graz = rng.random(n) < 0.15
+    e = b - a
+    e /= np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-30)
+    tilt = rng.normal(size=(n, 3)) * (10.0 ** rng.uniform(-7, -2, (n, 1)))
+    o = np.where(graz[:, None], a - e * rng.uniform(0.5, 30, (n, 1)) * ext, o)
+    d = np.where(graz[:, None], e + tilt, d)
+    # far origins aimed at vertices / edges: rounding of the exact test grows with the distance
+    far = (~graz) & (rng.random(n) < 0.15)
+    fo = tgt + (o - tgt) / np.maximum(np.linalg.norm(o - tgt, axis=1, keepdims=True), 1e-30) * (10.0 ** rng.uniform(1, 4, (n, 1))) * ext
+    o = np.where(far[:, None], fo, o)
+    d = np.where(far[:, None], tgt - fo, d)
     d = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
     return o.astype(np.float32), d.astype(np.float32)
 

@@ -23,7 +23,25 @@ SCENES = {
     "minecraft": lambda S: S.minecraft_like(res=(96, 54), ssaa=1, sample=2),
     "sink": lambda S: S.kitchen_sink(res=(96, 64), sample=8),
     "ragged": lambda S: S.cornell_box(res=(37, 23), ssaa=1.5, sample=3),
+    "bigmesh": lambda S: _big_mesh_scene(S),          # 20480 triangles: scene read through L2, triangle BVH route
+    "mesh_glass_inst": lambda S: _glass_mesh_instances(S),   # t1 / i1 (exit hit) of meshes, rotated + translated instances
 }
+
+
+def _big_mesh_scene(S):
+    d = S.mesh_scene(res=(64, 36), sample=2)
+    d["scene"]["renderer"][0]["mesh"] = [[[float(c) for c in v] for v in t] for t in S.icosphere(5, 0.45, (1.3, 1.0, 1.1))]
+    return d
+
+
+def _glass_mesh_instances(S):
+    d = S.mesh_scene(res=(80, 45), sample=4)
+    m = d["scene"]["renderer"][0]
+    m["mesh"] = [[[float(c) for c in v] for v in t] for t in S.icosphere(2, 0.3, (1.0, 1.2, 0.9))]
+    m["mat"] = {"rough": 0.1, "glass": 0.4, "opacity": 0.2, "albedo": [0.8, 0.9, 1.0]}
+    m.pop("pos", None)
+    m["inst"] = [[[-0.5, 0.6, 0.0], [0, 0, -1, 0]], [[0.3, 0.5, 0.1], [0.4, 0.2, -1, 0.3]], [[0.1, 1.4, -0.1], [-0.7, 1, 0.2, 0]]]
+    return d
 
 
 def _gpu_render(render, spp, seed=5, **kw):
