@@ -154,7 +154,13 @@ void build_octree(const float *tris, u32 n_tris, OctreeFlat &out)
 // Top-down sweep SAH on triangle centroids (median split above kSahMax triangles per node), leaves of at most
 // leaf_max items, nodes in depth-first order with skip links; `order` receives the triangles in leaf order.
 namespace {
-constexpr u32 kTbvhLeaf = 4;
+#ifndef MRT_TBVH_LEAF_MAX          // build-time experiment knobs (make EXTRA=-D...)
+#define MRT_TBVH_LEAF_MAX 4
+#endif
+#ifndef MRT_TBVH_CNODE
+#define MRT_TBVH_CNODE 1.0          // cost of the two extra box tests of a split, in triangle tests
+#endif
+constexpr u32 kTbvhLeaf = MRT_TBVH_LEAF_MAX;
 constexpr size_t kSahMax = 8192;
 struct TriBox { float mn[3], mx[3], c[3]; };
 struct TbvhBuild {
@@ -209,7 +215,7 @@ struct TbvhBuild {
                     }
                 }
                 // a small node stays a leaf when splitting does not pay for the two extra box tests
-                if (n <= leaf_max && !(best + 1.0 * area(mn, mx) < area(mn, mx) * (double)n)) best_ax = -1;
+                if (n <= leaf_max && !(best + MRT_TBVH_CNODE * area(mn, mx) < area(mn, mx) * (double)n)) best_ax = -1;
             }
         }
         if (best_ax < 0) {

@@ -82,4 +82,19 @@ def cases():
                                {"type": "sphere", "r": 0.3, "mat": {"albedo": "#ff2020"}, "inst": dup},
                                {"type": "sphere", "r": 0.3, "mat": {"albedo": "#2020ff"}, "inst": dup}]
     out["bvh_mixed_rotated_and_coincident"] = d
+
+    # ---- meshes: triangle-BVH route next to a mesh that cannot be bounded (reference walk), shared between instances ----
+    ico = [[[float(c) for c in v] for v in t] for t in scenes.icosphere(1, 0.35, (1.0, 1.2, 0.8))]
+    far = [[[float(c) for c in v] for v in t] for t in scenes.icosphere(0, 0.3)]
+    far[3][1][0] = 2.5e6                                                     # one vertex beyond the culling range: no TBVH for this mesh
+    dupm = [[[-0.6, 0.9, 0.1], [0, 0, -1, 0]]] * 2                         # coincident mesh instances: exact ties between equal triangles
+    d = _base(res=(40, 24), sample=3, bounce=4)
+    d["scene"]["renderer"] = [
+        {"type": "mesh", "mesh": ico, "mat": {"rough": 0.3, "albedo": "#ffb060"}, "inst": [[[0.5, 0.6, 0.0], [0, 0, -1, 0]], [[-0.1, 1.3, 0.3], [0.5, 0.3, -1, 0.2]]]},
+        {"type": "mesh", "mesh": far, "pos": [-0.7, 0.2, -0.1], "mat": {"glass": 0.6, "opacity": 0.3}},
+        {"type": "mesh", "mesh": ico, "mat": {"albedo": "#6080ff", "metal": 0.7}, "inst": dupm},
+        {"type": "mesh", "mesh": [], "pos": [0, 0, 0]},                                                # empty mesh: never hit
+        {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.5], "mat": {"rough": 1}}]
+    d["scene"]["light"] = [{"type": "point", "pos": [1.0, -1.5, 1.5], "pwr": 0.6}]
+    out["meshes_tbvh_unbounded_empty_coincident"] = d
     return out
