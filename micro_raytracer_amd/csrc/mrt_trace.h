@@ -35,6 +35,9 @@ enum : u32 {
 #ifndef MRT_COUNT
 #define MRT_COUNT(counter)
 #endif
+#ifndef MRT_PROBE_TBVH_PART            // (node, first node of the root's right subtree): which half of a triangle BVH is being walked
+#define MRT_PROBE_TBVH_PART(node, right0)
+#endif
 enum : u32 { CT_TRACE = 0, CT_LIN_TEST, CT_BVH_NODE, CT_BVH_TEST, CT_MESH_CALL, CT_MESH_ROOT_HIT, CT_TBVH_NODE, CT_TBVH_TRI, CT_TBVH_TRI_HIT, CT_MEMB_BOX, CT_TRACE_ANY, CT_COUNT };
 enum : u32 { PH_ITER = 0, PH_REGEN, PH_SPHERE_MATH, PH_PLANE_HIT, PH_SHADE, PH_NORMAL_NONPLANE, PH_SCATTER1, PH_SCATTER2, PH_REFRACT, PH_EMIT_END, PH_LIGHTS, PH_COUNT };
 
@@ -342,6 +345,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             u32 leaf = 0u, skip = BVH_END;
             while (node != BVH_END) {
                 const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
+                MRT_PROBE_TBVH_PART(node, f2u(B0[(tb + 1u) * BVH_WORDS + BVH_SKIP]));
                 MRT_COUNT(CT_TBVH_NODE);
                 skip = f2u(nb.z);
                 leaf = f2u(nb.w);

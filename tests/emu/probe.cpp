@@ -9,15 +9,19 @@
 #include <vector>
 
 static thread_local std::vector<uint16_t> *g_rec = nullptr;   // one bitmask per iteration
-#define MRT_PROBE(phase) do { if (g_work && (phase) == 0) { g_work->push_back(0); if (g_work_any) g_work_any->push_back(0); } if (g_rec) { if ((phase) == 0) g_rec->push_back(1); else g_rec->back() |= (uint16_t)(1u << (phase)); } } while (0)
+#define MRT_PROBE(phase) do { if (g_work && (phase) == 0) { g_work->push_back(0); if (g_work_any) g_work_any->push_back(0); if (g_work_r) { g_work_r->push_back(0); g_work_any_r->push_back(0); } } if (g_rec) { if ((phase) == 0) g_rec->push_back(1); else g_rec->back() |= (uint16_t)(1u << (phase)); } } while (0)
 
 static thread_local uint64_t g_cnt[32];
 static thread_local std::vector<uint32_t> *g_work = nullptr;   // per loop iteration: BVH / TBVH nodes + 3 x exact tests of the lane
 static thread_local std::vector<uint32_t> *g_work_any = nullptr;   // the same for the shadow queries of the iteration
 static thread_local bool g_in_any = false;
+static thread_local bool g_right = false;                           // walking the right half of a triangle BVH
+static thread_local std::vector<uint32_t> *g_work_r = nullptr, *g_work_any_r = nullptr;   // triangle-BVH work in right halves
+#define MRT_PROBE_TBVH_PART(node, right0) (g_right = (node) >= (right0))
 #define MRT_COUNT(counter) do { ++g_cnt[counter]; if ((counter) == 0) g_in_any = false; if ((counter) == 10) g_in_any = true; \
     if (g_work && !g_work->empty()) { std::vector<uint32_t> *w_ = (g_in_any && g_work_any) ? g_work_any : g_work; \
-        if ((counter) == 2 || (counter) == 6) w_->back() += 1; else if ((counter) == 1 || (counter) == 7) w_->back() += 3; } } while (0)
+        if ((counter) == 2 || (counter) == 6) w_->back() += 1; else if ((counter) == 1 || (counter) == 7) w_->back() += 3; \
+        if (g_work_r && g_right && ((counter) == 6 || (counter) == 7)) { std::vector<uint32_t> *r_ = g_in_any ? g_work_any_r : g_work_r; r_->back() += ((counter) == 6 ? 1 : 3); } } } while (0)
 
 #include "../../micro_raytracer_amd/csrc/mrt_pack.h"
 #include "../../micro_raytracer_amd/csrc/mrt_trace.h"
@@ -144,6 +148,34 @@ extern "C" int probe_tile_work(const mrt_render_desc *d, uint64_t seed, uint32_t
         g_work = nullptr; g_work_any = nullptr;
         const size_t n = w.size() < cap ? w.size() : cap;
         for (size_t k = 0; k < n; ++k) { out[(size_t)l * cap + k] = w[k]; out_any[(size_t)l * cap + k] = wa[k]; }
+        n_it[l] = (uint32_t)n;
+    }
+    return 0;
+}
+
+// probe_tile_work plus the part of the work that lies in the right half of the triangle BVHs (lane-pair splitting study)
+extern "C" int probe_tile_work_split(const mrt_render_desc *d, uint64_t seed, uint32_t n_samples, uint32_t tx, uint32_t ty, uint32_t cap,
+                                     uint32_t *out, uint32_t *out_any, uint32_t *out_r, uint32_t *out_any_r, uint32_t *n_it)
+{
+    Packed pk; std::string err;
+    if (pack_scene(d, pk, err)) return -1;
+    Params P = pk.P;
+    P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
+    P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.n_samples = n_samples; P.sample_base = 0; P.k_split = 1;
+    std::vector<float> frame((size_t)pk.nw * pk.nh * 3, 0.0f); P.accum = frame.data();
+    Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.G = S.F; S.P = &P;
+    for (int l = 0; l < 64; ++l) {
+        n_it[l] = 0;
+        const uint32_t x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
+        if (x >= pk.nw || y >= pk.nh) continue;
+        std::vector<uint32_t> w, wa, wr, war;
+        g_work = &w; g_work_any = &wa; g_work_r = &wr; g_work_any_r = &war;
+        u32 sg = 0; RegStash st;
+        LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u;
+        if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg);
+        g_work = nullptr; g_work_any = nullptr; g_work_r = nullptr; g_work_any_r = nullptr;
+        const size_t n = w.size() < cap ? w.size() : cap;
+        for (size_t k = 0; k < n; ++k) { out[(size_t)l * cap + k] = w[k]; out_any[(size_t)l * cap + k] = wa[k]; out_r[(size_t)l * cap + k] = wr[k]; out_any_r[(size_t)l * cap + k] = war[k]; }
         n_it[l] = (uint32_t)n;
     }
     return 0;
