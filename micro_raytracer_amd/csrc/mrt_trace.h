@@ -724,17 +724,6 @@ MRT_HD void camera_ray(const Params &P, V3 focus, u32 pk, V3 &o, V3 &d)
     o = add(pos, muls(d, kE));
 }
 
-// hides a value from the optimiser (see the loop in render_pixel)
-MRT_HD u32 opaque(u32 x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(x));
-#else
-    asm volatile("" : "+r"(x));
-#endif
-    return x;
-}
-
 // gen_bool(0.80) of src/rt.rs:564,579 takes the f64 literal 0.80: the threshold is floor(0.8 * 2^32), not the f32 0.8
 constexpr u32 kThr080 = 3435973836u;
 
