@@ -10,7 +10,7 @@ import sys
 tag = sys.argv[1]
 out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "cornell_1080p_1024spp_b8", "n_gpus": 1,
        "command": "python3 bench.py --no-cpu-baseline (trace) / --steps 1 --warmup 0 (pmc passes)"}
-ks = glob.glob(f"gpurun_out/{tag}_trace/*/*_kernel_stats.csv")
+ks = glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True)
 if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
     for r in csv.DictReader(open(ks[0])):
@@ -21,7 +21,7 @@ if ks:
             out["pct_gpu_time"] = float(r["Percentage"])
 pmc = {}
 meta = {}
-for f in sorted(glob.glob(f"gpurun_out/{tag}_pmc_*/*/*_counter_collection.csv")):
+for f in sorted(glob.glob(f"gpurun_out/{tag}_pmc_*/**/*counter_collection.csv", recursive=True)):
     one = collections.defaultdict(float)          # one --pmc pass = one launch of the kernel
     for r in csv.DictReader(open(f)):
         if "pt_megakernel" in r["Kernel_Name"]:
