@@ -341,27 +341,33 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
         }
         u32 s0 = 0, s1 = 0;
         u32 node = tb;
+        // "while-while" with one postponed leaf: a lane walks boxes until it has found two leaves (or the end), then the
+        // wavefront runs the exact triangle tests of both together -- fewer, fuller rounds than one leaf at a time.
         for (;;) {
-            u32 leaf = 0u, skip = BVH_END;
+            u32 leaf_a = 0u, leaf_b = 0u;
             while (node != BVH_END) {
                 const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
                 MRT_PROBE_TBVH_PART(node, f2u(B0[(tb + 1u) * BVH_WORDS + BVH_SKIP]));
                 MRT_COUNT(CT_TBVH_NODE);
-                skip = f2u(nb.z);
-                leaf = f2u(nb.w);
+                const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
                 // t = c * inv - o * inv -+ (h * |inv| + mg * |inv|)
                 const float px = fma_fast(na.x, R.inv.x, -oinv.x), py = fma_fast(na.y, R.inv.y, -oinv.y), pz = fma_fast(na.z, R.inv.z, -oinv.z);
                 const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);
                 const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
                 const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
                 if (tn > tf || tf < 0.0f) { node = skip; continue; }
-                if (leaf != 0u) break;
+                if (leaf != 0u) {
+                    node = skip;
+                    if (leaf_a == 0u) { leaf_a = leaf; continue; }
+                    leaf_b = leaf;
+                    break;
+                }
                 node = node + 1u;
             }
-            if (node == BVH_END) break;
-            const u32 cnt = leaf >> 24, first = leaf & 0xffffffu;
-            for (u32 j = 0; j < cnt; ++j) {
-                const u32 id = first + j;
+            if (leaf_a == 0u) break;
+            const u32 cnt_a = leaf_a >> 24, first_a = leaf_a & 0xffffffu, cnt_b = leaf_b >> 24, first_b = leaf_b & 0xffffffu;
+            for (u32 j = 0; j < cnt_a + cnt_b; ++j) {
+                const u32 id = j < cnt_a ? first_a + j : first_b + (j - cnt_a);
                 const float *T = F + P.off_tri + (tri0 + id) * TRI_WORDS;
                 float t;
                 MRT_COUNT(CT_TBVH_TRI);
@@ -394,7 +400,6 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                 if (k < k0 || (k == k0 && sl < s0)) { k0 = k; s0 = sl; t0 = t; i0 = (i32)id; }      // min_by: first minimum, src/rt.rs:764
                 if (k > k1 || (k == k1 && sh > s1)) { k1 = k; s1 = sh; t1 = t; i1 = (i32)id; }      // max_by: last maximum, src/rt.rs:765
             }
-            node = skip;
         }
         return any;
     }
@@ -538,12 +543,11 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         // "while-while": every lane first walks boxes until it stands on a leaf (cheap iterations, all lanes busy), then
         // the wavefront runs the expensive exact tests of the leaves together.
         for (;;) {
-            u32 leaf = 0u, skip = BVH_END;
+            u32 leaf_a = 0u, leaf_b = 0u;          // one postponed leaf, as in the triangle BVH
             while (node != BVH_END) {
                 const F4 na = ld4(N0, node * BVH_WORDS), nb = ld4(N0, node * BVH_WORDS + 4);
                 MRT_COUNT(CT_BVH_NODE);
-                skip = f2u(nb.z);
-                leaf = f2u(nb.w);
+                const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
                 bool hit_node = true;
                 if (cull) {
                     const V3 c = v3(na.x, na.y, na.z), hh = v3(na.w, nb.x, nb.y);
@@ -555,16 +559,20 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
                     if (!ANY && best.rend >= 0 && best.t0 >= 0.0f && tn > best.t0 + 1e-3f * best.t0 + mg) hit_node = false;
                 }
                 if (!hit_node) { node = skip; continue; }
-                if (leaf != 0u) break;
+                if (leaf != 0u) {
+                    node = skip;
+                    if (leaf_a == 0u) { leaf_a = leaf; continue; }
+                    leaf_b = leaf;
+                    break;
+                }
                 node = node + 1u;
             }
-            if (node == BVH_END) break;
-            const u32 cnt = leaf >> 24, first = leaf & 0xffffffu;
-            for (u32 k = 0; k < cnt; ++k) {
-                const u32 i = ldu(F, P.off_bvhinst + first + k);
+            if (leaf_a == 0u) break;
+            const u32 cnt_a = leaf_a >> 24, first_a = leaf_a & 0xffffffu, cnt_b = leaf_b >> 24, first_b = leaf_b & 0xffffffu;
+            for (u32 k = 0; k < cnt_a + cnt_b; ++k) {
+                const u32 i = ldu(F, P.off_bvhinst + (k < cnt_a ? first_a + k : first_b + (k - cnt_a)));
                 if (consider(i, ld4(I, i * INST_WORDS), ld4(I, i * INST_WORDS + 4))) return true;
             }
-            node = skip;
         }
     }
     if (best.rend < 0) return false;
