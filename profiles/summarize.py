@@ -1,5 +1,7 @@
 """Summarise rocprofv3 outputs (gpurun_out/<tag>_{trace,pmc_*}) into profiles/<tag>_* files.
-usage: python profiles/summarize.py r1b"""
+usage: python profiles/summarize.py <tag> [workload] [pmc_scale]
+pmc_scale = spp of the traced launch / spp of the PMC launches (collect.sh EXTRA="--spp N"): instruction counts scale
+with spp, so the derived per-launch instruction totals are multiplied by it to match avg_ms."""
 import collections
 import csv
 import glob
@@ -8,7 +10,8 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "cornell_1080p_1024spp_b8", "n_gpus": 1,
+pmc_scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "cornell_1080p_1024spp_b8", "n_gpus": 1, "pmc_scale": pmc_scale,
        "command": "python3 bench.py --no-cpu-baseline (trace) / --steps 1 --warmup 0 (pmc passes)"}
 ks = glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True)
 if ks:
@@ -33,12 +36,12 @@ out["pmc_per_launch"] = dict(pmc)
 out["dispatch"] = meta
 d = {}
 if "SQ_INSTS_VALU" in pmc:
-    d["valu_wave_instr"] = pmc["SQ_INSTS_VALU"]
+    d["valu_wave_instr"] = pmc["SQ_INSTS_VALU"] * pmc_scale
     d["lane_utilisation"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
 if "SQ_INSTS_VALU_FLOPS_FP32" in pmc and "SQ_INSTS_VALU" in pmc:
     # dynamic instruction mix (wave-instructions per launch); FLOPS_FP32 counts add + mul + 2 x fma + trans
     d["mix"] = {k.replace("SQ_INSTS_VALU_", "").lower(): pmc[k] / pmc["SQ_INSTS_VALU"] for k in pmc if k.startswith("SQ_INSTS_VALU_")}
-    d["fp32_flop_wave_instr"] = pmc["SQ_INSTS_VALU_FLOPS_FP32"]
+    d["fp32_flop_wave_instr"] = pmc["SQ_INSTS_VALU_FLOPS_FP32"] * pmc_scale
 if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc:
     d["wait_any_frac"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
     d["wait_inst_any_frac"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
