@@ -162,6 +162,7 @@ namespace {
 #endif
 constexpr u32 kTbvhLeaf = MRT_TBVH_LEAF_MAX;
 constexpr size_t kSahMax = 8192;
+constexpr u32 kSahDepth = 48;        // recursion stays shallow whatever the input (callers may run on small thread stacks)
 struct TriBox { float mn[3], mx[3], c[3]; };
 struct TbvhBuild {
     const std::vector<TriBox> &tb;
@@ -173,7 +174,7 @@ struct TbvhBuild {
         const double x = (double)mx[0] - mn[0], y = (double)mx[1] - mn[1], z = (double)mx[2] - mn[2];
         return x * y + y * z + z * x;
     }
-    void make(std::vector<u32> &v, size_t lo, size_t hi)
+    void make(std::vector<u32> &v, size_t lo, size_t hi, u32 depth = 0)
     {
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) {
@@ -188,7 +189,7 @@ struct TbvhBuild {
         size_t mid = 0;
         int best_ax = -1;
         if (n > 2) {
-            if (n > kSahMax) {
+            if (n > kSahMax || depth > kSahDepth) {      // big nodes, and chains of lopsided SAH splits, fall back to the median
                 float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
                 for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) { const float c = tb[v[k]].c[a]; if (c < cmn[a]) cmn[a] = c; if (c > cmx[a]) cmx[a] = c; }
                 best_ax = 0;
@@ -222,10 +223,10 @@ struct TbvhBuild {
             leaf = ((u32)n << 24) | (u32)order.size();
             for (size_t k = lo; k < hi; ++k) order.push_back(v[k]);
         } else {
-            if (n > kSahMax) std::nth_element(v.begin() + lo, v.begin() + mid, v.begin() + hi, [&](u32 x, u32 y) { return tb[x].c[best_ax] < tb[y].c[best_ax] || (tb[x].c[best_ax] == tb[y].c[best_ax] && x < y); });
+            if (n > kSahMax || depth > kSahDepth) std::nth_element(v.begin() + lo, v.begin() + mid, v.begin() + hi, [&](u32 x, u32 y) { return tb[x].c[best_ax] < tb[y].c[best_ax] || (tb[x].c[best_ax] == tb[y].c[best_ax] && x < y); });
             else if (best_ax != 2) std::sort(v.begin() + lo, v.begin() + hi, [&](u32 x, u32 y) { return tb[x].c[best_ax] < tb[y].c[best_ax] || (tb[x].c[best_ax] == tb[y].c[best_ax] && x < y); });
-            make(v, lo, mid);
-            make(v, mid, hi);
+            make(v, lo, mid, depth + 1);
+            make(v, mid, hi, depth + 1);
         }
         float *q = nodes.data() + (size_t)me * BVH_WORDS;
         for (int a = 0; a < 3; ++a) {
