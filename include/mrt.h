@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 1u
+#define MRT_ABI_VERSION 2u
 
 /* ---- error codes (reference: Result<_, String> everywhere, src/sampler.rs:80, src/cli.rs:155) ---- */
 #define MRT_OK            0
@@ -161,7 +161,7 @@ typedef struct mrt_ctx mrt_ctx;
 /* Counters of the most recent mrt_execute (reference: the Duration returned by
  * Sampler::execute, src/sampler.rs:35,77, logged at src/cli.rs:164). */
 typedef struct mrt_stats {
-    double   kernel_ms;      /* HIP-event time of the path-tracing kernel(s) of the last execute */
+    double   kernel_ms;      /* HIP-event time of the path-tracing kernel of the last execute    */
     double   gather_ms;      /* time of the multi-GPU gather (0 on one device)                   */
     uint64_t samples;        /* path samples traced by the last execute on this context          */
     uint64_t segments;       /* path segments (closest-hit queries) of the last execute          */
@@ -172,6 +172,7 @@ typedef struct mrt_stats {
     uint32_t k_split;        /* lanes per pixel of the last execute (sample chunks dealt round-robin) */
     uint32_t reserved;
     double   img_ms;         /* HIP-event time of the kernels of the last mrt_img / mrt_img_ss (tone map + resize) */
+    double   reduce_ms;      /* HIP-event time of reduce_chunks after the path-tracing kernel (0 when k_split == 1) */
 } mrt_stats;
 
 /* Sampler::new + the first half of Sampler::execute's argument list (src/sampler.rs:19,28):

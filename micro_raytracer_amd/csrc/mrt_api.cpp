@@ -80,7 +80,10 @@ constexpr size_t kTwoCopies = 68u * 1024u;          // <= this: two 256-thread w
 constexpr size_t kStash256 = 10u * 1024u + 256u;     // lane stash of a 256-thread workgroup (ST_SLOTS * 256 * 4 B, rounded up)
 constexpr size_t kOneCopyStash = 118u * 1024u;      // <= this: one 1024-thread workgroup with its 40 KB stash fits a CU
 constexpr size_t kSmallScene = 6u * 1024u;          // <= this: single-wave workgroups are allowed (24 LDS copies per CU)
-constexpr unsigned long long kSplitTargetWaves = 256ull * 24ull * 2ull;  // sample-split until two full rounds of 24 waves/CU
+// Sample-split until the launch has ~15 rounds of 32 waves per CU: shorter wavefronts balance the tail of a launch (tiles
+// differ in path length).  Measured on the 1080p x 1024 spp Cornell box (tests/gpu_shard_probe.py): whole frame 328 -> 315 ms
+// with 4 lanes per pixel, one shard of 8 GPUs 47.1 -> 42.4 ms with 16.
+constexpr unsigned long long kSplitTargetWaves = 120000ull;
 constexpr unsigned long long kSmallGridWaves = 256ull * 24ull * 3ull;   // fewer 8x8 tiles than three full rounds of 24 waves/CU
 
 }  // namespace
@@ -88,7 +91,7 @@ constexpr unsigned long long kSmallGridWaves = 256ull * 24ull * 3ull;   // fewer
 struct mrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
     Packed pk;
     Params P;
     u32 *d_blob = nullptr;
@@ -141,6 +144,7 @@ void free_ctx(mrt_ctx *c)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evm) (void)hipEventDestroy(c->evm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -195,6 +199,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
+    if ((e = hipEventCreate(&c->evm)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
     const size_t all_bytes = (size_t)c->pk.blob.size() * 4;
     if ((e = hipMalloc((void **)&c->d_blob, all_bytes ? all_bytes : 16)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
     if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), all_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
@@ -324,7 +329,7 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
 {
     int rc = set_device(c);
     if (rc) return rc;
-    c->stats.kernel_ms = 0; c->stats.gather_ms = 0; c->stats.launches = 0; c->stats.samples = 0; c->stats.segments = 0;
+    c->stats.kernel_ms = 0; c->stats.reduce_ms = 0; c->stats.gather_ms = 0; c->stats.launches = 0; c->stats.samples = 0; c->stats.segments = 0;
     if (!(n_samples && c->local_rows)) return MRT_OK;
     HIP_TRY(hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
     c->P.n_samples = n_samples;
@@ -351,6 +356,7 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
     c->stats.k_split = k_split;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
+    HIP_TRY(hipEventRecord(c->evm, c->stream));
     if (k_split > 1u) HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_partial, (size_t)c->local_rows * c->pk.nw * 3, plane, n_chunks, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     return MRT_OK;
@@ -363,7 +369,10 @@ static int exec_finish(mrt_ctx *c, uint32_t n_samples)
     if (n_samples && c->local_rows) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        float red = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
+        HIP_TRY(hipEventElapsedTime(&red, c->evm, c->ev1));
+        c->stats.reduce_ms = c->stats.k_split > 1u ? red : 0.0;
         unsigned long long seg = 0;
         HIP_TRY(hipMemcpy(&seg, c->d_segments, sizeof seg, hipMemcpyDeviceToHost));
         c->stats.kernel_ms = ms; c->stats.launches = 1; c->stats.segments = seg;
@@ -395,8 +404,10 @@ static int exec_group(mrt_ctx *g, uint32_t n_samples)
     g->count += n_samples;
     g->full_count = g->count;
     memset(&g->stats, 0, offsetof(mrt_stats, lds_bytes));
+    g->stats.reduce_ms = 0;
     for (mrt_ctx *s : g->subs) {
         if (s->stats.kernel_ms > g->stats.kernel_ms) g->stats.kernel_ms = s->stats.kernel_ms;
+        if (s->stats.reduce_ms > g->stats.reduce_ms) g->stats.reduce_ms = s->stats.reduce_ms;
         g->stats.samples += s->stats.samples; g->stats.segments += s->stats.segments; g->stats.launches += s->stats.launches;
     }
     g->stats.k_split = g->subs[0]->stats.k_split;

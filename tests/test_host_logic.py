@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mrt_abi_version() == 1
+    assert L.mrt_abi_version() == 2
 
 
 def test_no_device_fails_loudly_not_silently():
