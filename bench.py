@@ -181,8 +181,8 @@ def main():
         # = accumulator read + write (12 B + 12 B per owned pixel) + one read of the packed scene
         px_local = ss.s.local_rows * nw
         alg_bytes = 24.0 * px_local + st["scene_bytes"]
-        if st["k_split"] > 1:          # sample split: one f32x3 chunk-sum plane per 16 samples, written once and read once by reduce_chunks
-            alg_bytes += 24.0 * px_local * ((spp + 15) // 16)
+        if st["k_split"] > 1:          # sample split: pt_megakernel writes one f32x3 chunk sum per pixel per 16 samples (reduce_chunks,
+            alg_bytes = 12.0 * px_local * ((spp + 15) // 16) + st["scene_bytes"]     # timed apart, folds them into the accumulator)
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         seg_local = segments / max(1, args.steps)
@@ -198,7 +198,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (pmc_traffic(args.workload, world) or (None, None))[0] if not args.spp else None,
                          "traffic_source": (pmc_traffic(args.workload, world) or (None, None))[1] if not args.spp else None, "kernel": "pt_megakernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "by construction not HBM-bound (SURVEY.md §8d): the scene lives in LDS, HBM sees 24 B per pixel per launch plus, with sample split, one 12 B chunk sum per pixel per 16 samples written and read back once (kernel_ms is pt_megakernel alone; reduce_chunks: reduce_ms)", "reduce_ms": st.get("reduce_ms")},
+                         "note": "by construction not HBM-bound (SURVEY.md §8d): the scene lives in LDS, HBM sees 24 B per pixel per launch, or with sample split one 12 B chunk sum per pixel per 16 samples, which reduce_chunks (reduce_ms) then folds into the accumulator; kernel_ms is pt_megakernel alone", "reduce_ms": st.get("reduce_ms")},
             "valu": {"achieved_tflops": valu_tflops, "peak_tflops": VALU_PEAK_TFLOPS, "frac": valu_tflops / VALU_PEAK_TFLOPS,
                      "segments_per_sample": total_segments / samples, "flop_per_segment_model": FLOP_PER_SEGMENT,
                      "Gsegments_per_s": total_segments / elapsed / 1e9},
