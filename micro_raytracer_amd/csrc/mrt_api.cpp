@@ -84,7 +84,6 @@ constexpr size_t kSmallScene = 6u * 1024u;          // <= this: single-wave work
 // differ in path length).  Measured on the 1080p x 1024 spp Cornell box (tests/gpu_shard_probe.py): whole frame 328 -> 315 ms
 // with 4 lanes per pixel, one shard of 8 GPUs 47.1 -> 42.4 ms with 16.
 constexpr unsigned long long kSplitTargetWaves = 120000ull;
-constexpr unsigned long long kSmallGridWaves = 256ull * 24ull * 3ull;   // fewer 8x8 tiles than three full rounds of 24 waves/CU
 
 }  // namespace
 
@@ -219,18 +218,17 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     // launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
     // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most.
     //   256 threads (2x2 wave tiles of 8x8 pixels) + 10 KB lane stash per copy of the scene;
-    //   64 threads instead when this context owns few tiles (small frames, one shard of a multi-GPU frame);
+    //   64 threads instead when the scene is small enough for ~29 LDS copies per CU (<= 6 KB);
     //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves;
     //   scenes that do not fit the LDS are read through L2.
     c->scene_in_lds = blob_bytes + 1024 <= kLdsLimit && !getenv("MRT_SCENE_IN_L2");      // env: experiments only
-    const unsigned long long wave_tiles = (unsigned long long)((nw + 7) / 8) * ((c->local_rows + 7) / 8);
     const char *force = getenv("MRT_BLOCK_THREADS");      // experiments only
     u32 want = 256u;
     if (c->scene_in_lds) {
         const size_t w256 = 4u * (kLdsLimit / (blob_bytes + kStash256));
         const size_t w512 = 8u * (kLdsLimit / (blob_bytes ? blob_bytes : 1));
         const size_t w1024 = blob_bytes <= kOneCopyStash ? 16u : 0u;
-        if (w256 >= 16u) want = (wave_tiles < kSmallGridWaves && blob_bytes <= kSmallScene) ? 64u : 256u;
+        if (w256 >= 16u) want = blob_bytes <= kSmallScene ? 64u : 256u;      // single-wave workgroups schedule finest: +1 % on the Cornell scenes at any frame size
         else if (w512 >= 16u) want = 512u;
         else if (w1024 >= 16u) want = 1024u;
         else want = (w256 >= w512 && blob_bytes <= kTwoCopies) ? 256u : 512u;
