@@ -212,8 +212,8 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipMalloc((void **)&c->d_accum_own, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(accumulator)", e);
     c->d_accum = c->d_accum_own;
     if ((e = hipMemset(c->d_accum, 0, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
-    if ((e = hipMalloc((void **)&c->d_segments, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);
-    if ((e = hipMemset(c->d_segments, 0, sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
+    if ((e = hipMalloc((void **)&c->d_segments, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);   // + tile counter
+    if ((e = hipMemset(c->d_segments, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
 
     // launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
     // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most.
@@ -248,6 +248,18 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     c->P.local_rows = c->local_rows; c->P.shard_index = c->shard_index; c->P.shard_count = c->shard_count; c->P.shard_rows = c->shard_rows;
     c->P.seed_lo = (u32)c->seed; c->P.seed_hi = (u32)(c->seed >> 32);
     c->P.blob = c->d_blob; c->P.accum = c->d_accum; c->P.segments = c->d_segments;
+    c->P.tile_counter = reinterpret_cast<u32 *>(c->d_segments + 1);
+    {
+        // persistent launches (workgroups of more than one wavefront): as many workgroups as fit the device at once; each
+        // wavefront then draws 8x8 tiles from a counter, so no CU waits for the slowest wavefront of a workgroup
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n_cu <= 0) n_cu = 256;
+        const size_t lds = pt_lds_bytes(c->pk.P, c->block_threads, c->scene_in_lds, c->pk.features);
+        size_t per_cu = 32u / (c->block_threads / 64u);
+        if (lds && kLdsLimit / lds < per_cu) per_cu = kLdsLimit / lds;
+        if (per_cu < 1u) per_cu = 1u;
+        c->P.persist_grid = c->block_threads > 64u && !getenv("MRT_NO_PERSIST") ? (u32)(n_cu * per_cu) : 0u;
+    }
     c->P.count_segments = 1;
     memset(&c->stats, 0, sizeof c->stats);
     c->stats.lds_bytes = (u32)pt_lds_bytes(c->pk.P, c->block_threads, c->scene_in_lds, c->pk.features);
@@ -329,7 +341,7 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
     if (rc) return rc;
     c->stats.kernel_ms = 0; c->stats.reduce_ms = 0; c->stats.gather_ms = 0; c->stats.launches = 0; c->stats.samples = 0; c->stats.segments = 0;
     if (!(n_samples && c->local_rows)) return MRT_OK;
-    HIP_TRY(hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_segments, 0, 2 * sizeof(unsigned long long), c->stream));
     c->P.n_samples = n_samples;
     c->P.sample_base = c->count;
     // sample split: spread a small frame over more wavefronts, one lane per (pixel, every k-th sample chunk)

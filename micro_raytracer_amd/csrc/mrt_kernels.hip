@@ -59,37 +59,60 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
     }
 
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u32 wx = wave % P.tiles_x, wy = wave / P.tiles_x;
-    const u32 x = (blockIdx.x * P.tiles_x + wx) * 8u + (lane & 7u);
-    const u32 ry = (blockIdx.y * P.tiles_y + wy) * 8u + (lane >> 3);
-    // shard-local row -> frame row: row block b of this shard is frame row block b * shard_count + shard_index
-    const u32 blk = ry / P.shard_rows;
-    const u32 y = (blk * P.shard_count + P.shard_index) * P.shard_rows + (ry - blk * P.shard_rows);
-    const bool active = x < P.nw && ry < P.local_rows && y < P.nh;
-
-    u32 segments = 0;
-    if (active) {
-        Scn S;
-        S.F = F;
+    Scn S;
+    S.F = F;
 #ifdef MRT_UNIFORM_SMEM
-        S.U = reinterpret_cast<const float *>(blob_g);
+    S.U = reinterpret_cast<const float *>(blob_g);
 #else
-        S.U = F;
+    S.U = F;
 #endif
-        S.G = reinterpret_cast<const float *>(blob_g);
-        S.P = &P;
+    S.G = reinterpret_cast<const float *>(blob_g);
+    S.P = &P;
+    u32 segments = 0;
+    // one 8x8 tile of shard-local rows for this wavefront, lane k of the sample split
+    auto do_tile = [&](u32 tx, u32 ty, u32 k) {
+        const u32 x = tx * 8u + (lane & 7u);
+        const u32 ry = ty * 8u + (lane >> 3);
+        // shard-local row -> frame row: row block b of this shard is frame row block b * shard_count + shard_index
+        const u32 blk = ry / P.shard_rows;
+        const u32 y = (blk * P.shard_count + P.shard_index) * P.shard_rows + (ry - blk * P.shard_rows);
+        const bool active = x < P.nw && ry < P.local_rows && y < P.nh;
+        if (!active) return;
+        u32 seg = 0;
         LaneJob job;
-        job.k = blockIdx.z;
+        job.k = k;
         job.word = (ry * P.nw + x) * 3u;        // < 2^32: mrt_create limits a shard to 2^30 pixels
         if constexpr (lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
             LdsStash<BLOCK_THREADS> st;
             st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + ((P.lds_words + 3u) >> 2)) + threadIdx.x);
-            render_pixel<FEAT>(S, st, x, y, job, segments);
+            render_pixel<FEAT>(S, st, x, y, job, seg);
         } else {
             RegStash st;
-            render_pixel<FEAT>(S, st, x, y, job, segments);
+            render_pixel<FEAT>(S, st, x, y, job, seg);
         }
+        segments += seg;
+    };
+    // Persistent workgroup (more than one wavefront, P.persist_grid set): its wavefronts draw tiles from a counter until the
+    // launch is out of tiles, so a CU never waits for the slowest wavefront of a workgroup (whose LDS copy of the scene
+    // would otherwise keep the next workgroup out).  Otherwise blockIdx addresses the one tile of each wavefront.
+    const bool persist = BLOCK_THREADS > 64 && P.persist_grid != 0u;
+    const u32 n_tx = (P.nw + 7u) >> 3, n_ty = (P.local_rows + 7u) >> 3;
+    const u32 per_k = n_tx * n_ty, total = per_k * P.k_split;
+    for (;;) {
+        u32 tx = blockIdx.x * P.tiles_x + wave % P.tiles_x, ty = blockIdx.y * P.tiles_y + wave / P.tiles_x, k = blockIdx.z;
+        if (persist) {
+            u32 t = 0;
+            if (lane == 0) t = atomicAdd(P.tile_counter, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= total) break;
+            k = t / per_k;
+            const u32 r = t - k * per_k;
+            ty = r / n_tx;
+            tx = r - ty * n_tx;
+        }
+        do_tile(tx, ty, k);
+        if (!persist) break;
     }
     if (P.count_segments) {
         // wave-level sum (every lane of the wavefront is here), one atomic per wavefront
@@ -221,6 +244,10 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     if (block_threads != P.tiles_x * P.tiles_y * 64u) return hipErrorInvalidConfiguration;
     const u32 tile_w = P.tiles_x * 8u, tile_h = P.tiles_y * 8u;
     dim3 grid((P.nw + tile_w - 1) / tile_w, (P.local_rows + tile_h - 1) / tile_h, P.k_split);
+    if (block_threads > 64u && P.persist_grid) {
+        const unsigned long long n_wg = (unsigned long long)grid.x * grid.y * grid.z;
+        grid = dim3((unsigned)(n_wg < P.persist_grid ? n_wg : P.persist_grid), 1, 1);
+    }
     const size_t lds = pt_lds_bytes(P, block_threads, scene_in_lds, features);
     if (features & F_BVH) {         // many-instance scenes: one all-features + BVH instantiation per launch shape
         if (!scene_in_lds) { if (block_threads != 256u) return hipErrorInvalidConfiguration; hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL | F_BVH>), grid, dim3(256), 0, stream, P, P.blob); }

@@ -127,6 +127,8 @@ struct Params {
     float *partial;          // [chunks of this launch][padded_rows][nw][3], used when k_split > 1
     unsigned long long partial_stride;   // floats per chunk plane
     unsigned long long *segments;
+    u32 *tile_counter;       // persistent launches: next (tile, sample-split lane) index, zeroed before the launch
+    u32 persist_grid;        // workgroups of a persistent launch (0: one workgroup per tile block, blockIdx addresses the tiles)
 };
 
 }  // namespace mrt
