@@ -231,13 +231,14 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         if (w256 >= 16u) want = blob_bytes <= kSmallScene ? 64u : 256u;      // single-wave workgroups schedule finest: +1 % on the Cornell scenes at any frame size
         else if (w512 >= 16u) want = 512u;
         else if (w1024 >= 16u) want = 1024u;
-        else want = (w256 >= w512 && blob_bytes <= kTwoCopies) ? 256u : 512u;
+        else if (w256 >= w512 && blob_bytes <= kTwoCopies) want = 256u;
+        else { want = 1024u; c->pk.features |= 32u; }      // F_NOSTASH: one LDS copy for 16 waves, lane state in registers
     }
     if (force && c->scene_in_lds) {
         const u32 f = (u32)atoi(force);
-        if ((f == 64u || f == 256u) && blob_bytes <= kTwoCopies) want = f;
-        if (f == 1024u && blob_bytes <= kOneCopyStash) want = f;
-        if (f == 512u) want = f;
+        if ((f == 64u || f == 256u) && blob_bytes <= kTwoCopies) { want = f; c->pk.features &= ~32u; }
+        if (f == 1024u && blob_bytes <= kOneCopyStash) { want = f; c->pk.features &= ~32u; }
+        if (f == 512u) { want = f; c->pk.features &= ~32u; }
     }
     c->block_threads = want;
     c->pk.P.tiles_x = want == 64u ? 1u : (want == 256u ? 2u : 4u);

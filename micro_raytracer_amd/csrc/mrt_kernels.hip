@@ -26,12 +26,12 @@ namespace mrt {
 // spills than they gain from occupancy and keep the compiler's choice.  MRT_WAVES_PER_EU overrides (experiments).
 // The per-path LDS stash (mrt_trace.h) is used by every launch shape that has room for it next to the scene: the
 // 64- and 256-thread workgroups with the scene in LDS.  It moves 7-25 VGPRs of rarely touched state out of the loop.
-constexpr bool lds_stash_for(bool scene_in_lds, int block_threads)
+constexpr bool lds_stash_for(bool scene_in_lds, int block_threads, u32 feat)
 {
 #ifdef MRT_NO_STASH
     return false;
 #else
-    return scene_in_lds && block_threads != 512;
+    return scene_in_lds && block_threads != 512 && !(feat & F_NOSTASH);
 #endif
 }
 constexpr int waves_for(u32 feat)
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         LaneJob job;
         job.k = k;
         job.word = (ry * P.nw + x) * 3u;        // < 2^32: mrt_create limits a shard to 2^30 pixels
-        if constexpr (lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS)) {
+        if constexpr (lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS, FEAT)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
             LdsStash<BLOCK_THREADS> st;
             st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + ((P.lds_words + 3u) >> 2)) + threadIdx.x);
@@ -235,7 +235,7 @@ size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 f
 {
     if (!scene_in_lds) return 0;
     size_t lds = (size_t)P.lds_words * 4u;
-    if (lds_stash_for(scene_in_lds, (int)block_threads)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
+    if (lds_stash_for(scene_in_lds, (int)block_threads, features)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
     return lds;
 }
 
@@ -254,6 +254,7 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
         else if (block_threads == 64u) launch_lds<64, F_ALL | F_BVH>(grid, lds, stream, P);
         else if (block_threads == 256u) launch_lds<256, F_ALL | F_BVH>(grid, lds, stream, P);
         else if (block_threads == 512u) launch_lds<512, F_ALL | F_BVH>(grid, lds, stream, P);
+        else if (block_threads == 1024u && (features & F_NOSTASH)) launch_lds<1024, F_ALL | F_BVH | F_NOSTASH>(grid, lds, stream, P);
         else if (block_threads == 1024u) launch_lds<1024, F_ALL | F_BVH>(grid, lds, stream, P);
         else return hipErrorInvalidConfiguration;
         return hipGetLastError();
@@ -262,6 +263,7 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
         if (block_threads == 256u) kLds256[features & F_ALL](grid, lds, stream, P);
         else if (block_threads == 64u) kLds64[features & F_ALL](grid, lds, stream, P);
         else if (block_threads == 512u) hipLaunchKernelGGL((pt_megakernel<true, 512, F_ALL>), grid, dim3(512), lds, stream, P, P.blob);
+        else if (block_threads == 1024u && (features & F_NOSTASH)) launch_lds<1024, F_ALL | F_NOSTASH>(grid, lds, stream, P);
         else if (block_threads == 1024u) hipLaunchKernelGGL((pt_megakernel<true, 1024, F_ALL>), grid, dim3(1024), lds, stream, P, P.blob);
         else return hipErrorInvalidConfiguration;
     } else {
@@ -290,6 +292,8 @@ hipError_t configure_pt(size_t max_lds_bytes)
     if ((e = set_lds_attr<256, F_ALL | F_BVH>(b)) != hipSuccess) return e;
     if ((e = set_lds_attr<512, F_ALL | F_BVH>(b)) != hipSuccess) return e;
     if ((e = set_lds_attr<1024, F_ALL | F_BVH>(b)) != hipSuccess) return e;
+    if ((e = set_lds_attr<1024, F_ALL | F_NOSTASH>(b)) != hipSuccess) return e;
+    if ((e = set_lds_attr<1024, F_ALL | F_BVH | F_NOSTASH>(b)) != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 512, F_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
 }
 

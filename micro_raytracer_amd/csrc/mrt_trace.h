@@ -24,7 +24,8 @@ enum : u32 {
     F_MAPS = 4u,      // some material has a texture map
     F_LIGHTS = 8u,    // the scene has lights (shadow rays + direct term)
     F_ALL = 15u,
-    F_BVH = 16u       // many instances: a BVH over them replaces most of the linear scan (only built with F_ALL)
+    F_BVH = 16u,      // many instances: a BVH over them replaces most of the linear scan (only built with F_ALL)
+    F_NOSTASH = 32u   // launch-shape marker, not a scene feature: 1024-thread workgroup whose scene leaves no LDS for the lane stash
 };
 
 // Divergence probe: only the x86 build of tests/emu defines MRT_PROBE(phase); in the kernel it is nothing.
