@@ -23,6 +23,8 @@ SCENES = {
     "minecraft": lambda S: S.minecraft_like(res=(96, 54), ssaa=1, sample=2),
     "sink": lambda S: S.kitchen_sink(res=(96, 64), sample=8),
     "ragged": lambda S: S.cornell_box(res=(37, 23), ssaa=1.5, sample=3),
+    "mesh1280": lambda S: S.mesh_scene(res=(64, 36), sample=2, n_tris=1280),   # 131 KB scene: 1024 threads, lane state in registers
+    "instance_1728": lambda S: S.instance_grid(res=(64, 36), sample=2, n=12),    # ~150 KB scene with the instance BVH, same shape
     "bigmesh": lambda S: _big_mesh_scene(S),          # 20480 triangles: scene read through L2, triangle BVH route
     "mesh_glass_inst": lambda S: _glass_mesh_instances(S),   # t1 / i1 (exit hit) of meshes, rotated + translated instances
 }
