@@ -107,6 +107,11 @@ class ShardedSampler:
         self.count += n_samples
         if gather:
             gather_frame(self.local, self.nh, self.nw, self.shard_rows, dst=0, out=self.frame)
+            if self.world > 1:
+                # like mrt_execute, return only when the exchange is done: the next launch (on the library's own stream)
+                # accumulates into the buffer the collective is still reading
+                import torch
+                torch.cuda.current_stream(self.dev).synchronize()
         return secs
 
     def img(self):
