@@ -901,10 +901,11 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                         const float *Lt = S.F + P.off_light + li * LIGHT_WORDS;
                         const bool point = ldu(Lt, LIGHT_KIND) == LK_POINT;
                         const V3 lv = ld3(Lt, LIGHT_V);
-                        const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
-                        const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
-                        Hit hs;
-                        if (trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs)) continue;
+                        // The light's term of the fold (src/rt.rs:973-987), evaluated before its shadow ray: when it is exactly zero
+                        // (surface facing away and no highlight: diff == 0, spec == 0) the light's visibility cannot change l_col
+                        // -- l_col is never -0, so adding +-0 leaves every bit -- and the shadow ray (src/rt.rs:1027-1045, a
+                        // whole any-hit traversal) is not traced.  A NaN anywhere in the term compares unequal to zero and takes
+                        // the reference's route.
                         const V3 ln = point ? norm(sub(lv, hp)) : lv;             // l.norm() at the recorded hit
                         const float diff = fmax_(dot(ln, hn), 0.0f);
                         const float sp = fmax_(dot(d, reflect(ln, hn)), 0.0f);
@@ -913,7 +914,13 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                         const V3 o_col = muls(color, 1.0f - metal_h);
                         V3 t = hadam(muls(o_col, diff), ld3(Lt, LIGHT_COLOR));
                         t = v3(t.x + spec, t.y + spec, t.z + spec);
-                        l_col = add(l_col, muls(t, Lt[LIGHT_PWR]));
+                        const V3 term = muls(t, Lt[LIGHT_PWR]);
+                        if (term.x == 0.0f && term.y == 0.0f && term.z == 0.0f) continue;
+                        const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
+                        const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
+                        Hit hs;
+                        if (trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs)) continue;
+                        l_col = add(l_col, term);
                     }
                     // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
                     L = add(L, hadam(T, muls(l_col, pwr)));

@@ -44,3 +44,8 @@ run("mesh without the light", m2, 64)
 if os.environ.get("MID"):
     for n in (300, 500, 700):
         run(f"mesh {n} tris", scenes.mesh_scene(res=(1920, 1080), sample=64, n_tris=n), 64)
+if os.environ.get("BIG"):
+    for n in (1600, 2500, 5120):
+        d = scenes.mesh_scene(res=(1920, 1080), sample=16)
+        d["scene"]["renderer"][0]["mesh"] = [[[float(c) for c in v] for v in t] for t in scenes.icosphere(4, 0.45, (1.3, 1.0, 1.1))[:n]]
+        run(f"mesh {n} tris (icosphere 4)", d, 16)
