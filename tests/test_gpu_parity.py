@@ -157,6 +157,24 @@ def test_sample_split_launch_is_bit_identical(monkeypatch):
     assert np.array_equal(sa.accum()[0], r1)
 
 
+def test_persistent_workgroups_change_no_bit(monkeypatch):
+    """Multi-wavefront workgroups draw their tiles from a counter (csrc/mrt_kernels.hip); which wavefront renders a tile
+    must not matter: the fixed blockIdx -> tile mapping (MRT_NO_PERSIST) gives the same accumulator bits."""
+    from micro_raytracer_amd import scenes
+    for desc in (scenes.mesh_scene(res=(200, 120), sample=32), scenes.minecraft_like(res=(96, 54), ssaa=2, sample=16)):
+        render, _ = make_holder(desc)
+        spp = render.rt.sample
+        a = _gpu_render(render, spp)
+        assert a.stats()["block_threads"] > 64
+        ra, _ = a.accum()
+        monkeypatch.setenv("MRT_NO_PERSIST", "1")
+        b = _gpu_render(render, spp)
+        rb, _ = b.accum()
+        monkeypatch.delenv("MRT_NO_PERSIST")
+        assert np.array_equal(ra.view(np.uint32), rb.view(np.uint32))
+        a.close(); b.close()
+
+
 def test_shards_reassemble_to_whole_frame():
     """Row shards (block-cyclic, 8-row blocks) of 3 contexts tile the single-context frame bit for bit."""
     from micro_raytracer_amd import scenes
