@@ -157,6 +157,9 @@ namespace {
 #ifndef MRT_TBVH_LEAF_MAX          // build-time experiment knobs (make EXTRA=-D...)
 #define MRT_TBVH_LEAF_MAX 4
 #endif
+#ifndef MRT_IBVH_LEAF_MAX
+#define MRT_IBVH_LEAF_MAX 2u
+#endif
 #ifndef MRT_TBVH_CNODE
 #define MRT_TBVH_CNODE 1.0          // cost of the two extra box tests of a split, in triangle tests
 #endif
@@ -188,7 +191,7 @@ struct TbvhBuild {
         u32 leaf = 0;
         size_t mid = 0;
         int best_ax = -1;
-        if (n > 2) {
+        if (n > (leaf_max < 2u ? leaf_max : 2u)) {
             if (n > kSahMax || depth > kSahDepth) {      // big nodes, and chains of lopsided SAH splits, fall back to the median
                 float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
                 for (size_t k = lo; k < hi; ++k) for (int a = 0; a < 3; ++a) { const float c = tb[v[k]].c[a]; if (c < cmn[a]) cmn[a] = c; if (c > cmx[a]) cmx[a] = c; }
@@ -604,7 +607,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
         } else {
             std::vector<TriBox> ib(n_inst_total);
             for (u32 i : elig) for (int a = 0; a < 3; ++a) { ib[i].mn[a] = bounds[i].mn[a]; ib[i].mx[a] = bounds[i].mx[a]; ib[i].c[a] = 0.5f * bounds[i].mn[a] + 0.5f * bounds[i].mx[a]; }
-            TbvhBuild build{ib, bvh_nodes, bvh_inst, 2u};
+            TbvhBuild build{ib, bvh_nodes, bvh_inst, MRT_IBVH_LEAF_MAX};
             build.make(elig, 0, elig.size());
             const u32 n_nodes = (u32)(bvh_nodes.size() / BVH_WORDS);
             for (u32 k = 0; k < n_nodes; ++k) { float *q = bvh_nodes.data() + (size_t)k * BVH_WORDS; if (bits(q[BVH_SKIP]) >= n_nodes) q[BVH_SKIP] = fbits(BVH_END); }
