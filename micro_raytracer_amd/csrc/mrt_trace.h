@@ -346,7 +346,10 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
         // wavefront runs the exact triangle tests of both together -- fewer, fuller rounds than one leaf at a time.
         for (;;) {
             u32 leaf_a = 0u, leaf_b = 0u;
-            while (node != BVH_END) {
+            // branch-free step: the only branch of the box walk is its wave-uniform exit; a lane that is done (end of the
+            // tree, or two leaves in hand) keeps re-reading the root and changes nothing
+            bool walking = node != BVH_END;
+            while (walking) {
                 const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
                 MRT_PROBE_TBVH_PART(node, f2u(B0[(tb + 1u) * BVH_WORDS + BVH_SKIP]));
                 MRT_COUNT(CT_TBVH_NODE);
@@ -356,14 +359,12 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                 const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);
                 const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
                 const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
-                if (tn > tf || tf < 0.0f) { node = skip; continue; }
-                if (leaf != 0u) {
-                    node = skip;
-                    if (leaf_a == 0u) { leaf_a = leaf; continue; }
-                    leaf_b = leaf;
-                    break;
-                }
-                node = node + 1u;
+                const bool hit = !(tn > tf || tf < 0.0f);
+                const bool take = hit && leaf != 0u;
+                leaf_b = (take && leaf_a != 0u) ? leaf : leaf_b;
+                leaf_a = (take && leaf_a == 0u) ? leaf : leaf_a;
+                node = (hit && leaf == 0u) ? node + 1u : skip;
+                walking = node != BVH_END && leaf_b == 0u;
             }
             if (leaf_a == 0u) break;
             const u32 cnt_a = leaf_a >> 24, first_a = leaf_a & 0xffffffu, cnt_b = leaf_b >> 24, first_b = leaf_b & 0xffffffu;
@@ -545,28 +546,24 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         // the wavefront runs the expensive exact tests of the leaves together.
         for (;;) {
             u32 leaf_a = 0u, leaf_b = 0u;          // one postponed leaf, as in the triangle BVH
-            while (node != BVH_END) {
+            bool walking = node != BVH_END;        // branch-free step: the loop's only branch is its exit
+            while (walking) {
                 const F4 na = ld4(N0, node * BVH_WORDS), nb = ld4(N0, node * BVH_WORDS + 4);
                 MRT_COUNT(CT_BVH_NODE);
                 const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
-                bool hit_node = true;
-                if (cull) {
-                    const V3 c = v3(na.x, na.y, na.z), hh = v3(na.w, nb.x, nb.y);
-                    const V3 r = sub(c, R.o);
-                    const float mg = cull_margin(kMarginInst, r, hh, obig + obig);
-                    float tn;
-                    hit_node = cull_slab(R, r, hh, mg, tn);
-                    // nothing in a node whose near side lies beyond the current closest hit can win
-                    if (!ANY && best.rend >= 0 && best.t0 >= 0.0f && tn > best.t0 + 1e-3f * best.t0 + mg) hit_node = false;
-                }
-                if (!hit_node) { node = skip; continue; }
-                if (leaf != 0u) {
-                    node = skip;
-                    if (leaf_a == 0u) { leaf_a = leaf; continue; }
-                    leaf_b = leaf;
-                    break;
-                }
-                node = node + 1u;
+                const V3 c = v3(na.x, na.y, na.z), hh = v3(na.w, nb.x, nb.y);
+                const V3 r = sub(c, R.o);
+                const float mg = cull_margin(kMarginInst, r, hh, obig + obig);
+                float tn;
+                bool hit_node = cull_slab(R, r, hh, mg, tn);
+                // nothing in a node whose near side lies beyond the current closest hit can win
+                if (!ANY) hit_node = hit_node && !(best.rend >= 0 && best.t0 >= 0.0f && tn > best.t0 + 1e-3f * best.t0 + mg);
+                hit_node = hit_node || !cull;      // rays that must not be culled visit everything
+                const bool take = hit_node && leaf != 0u;
+                leaf_b = (take && leaf_a != 0u) ? leaf : leaf_b;
+                leaf_a = (take && leaf_a == 0u) ? leaf : leaf_a;
+                node = (hit_node && leaf == 0u) ? node + 1u : skip;
+                walking = node != BVH_END && leaf_b == 0u;
             }
             if (leaf_a == 0u) break;
             const u32 cnt_a = leaf_a >> 24, first_a = leaf_a & 0xffffffu, cnt_b = leaf_b >> 24, first_b = leaf_b & 0xffffffu;
