@@ -175,6 +175,34 @@ def test_persistent_workgroups_change_no_bit(monkeypatch):
         a.close(); b.close()
 
 
+def test_every_launch_shape_gives_the_same_bits(monkeypatch):
+    """The launch shape (64 / 256 / 512 / 1024 threads, scene in LDS or read through L2, persistent or not) is a pure
+    scheduling choice: the same scene must give the same accumulator bits through every kernel instantiation."""
+    from micro_raytracer_amd import scenes
+    for desc in (scenes.cornell_box(res=(96, 64), sample=32), scenes.kitchen_sink(res=(80, 48), sample=16),
+                 scenes.minecraft_like(res=(64, 40), ssaa=1, sample=16)):
+        render, _ = make_holder(desc)
+        spp = render.rt.sample
+        ref = None
+        seen = set()
+        for threads, l2 in ((None, False), ("64", False), ("256", False), ("512", False), ("1024", False), (None, True)):
+            if threads:
+                monkeypatch.setenv("MRT_BLOCK_THREADS", threads)
+            if l2:
+                monkeypatch.setenv("MRT_SCENE_IN_L2", "1")
+            s = _gpu_render(render, spp)
+            got, _ = s.accum()
+            st = s.stats()
+            seen.add((st["block_threads"], st["lds_bytes"] > 0))
+            s.close()
+            monkeypatch.delenv("MRT_BLOCK_THREADS", raising=False)
+            monkeypatch.delenv("MRT_SCENE_IN_L2", raising=False)
+            if ref is None:
+                ref = got
+            assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (threads, l2)
+        assert len(seen) >= 3          # the shapes really differed (big scenes refuse the small workgroups)
+
+
 def test_shards_reassemble_to_whole_frame():
     """Row shards (block-cyclic, 8-row blocks) of 3 contexts tile the single-context frame bit for bit."""
     from micro_raytracer_amd import scenes
