@@ -1,0 +1,35 @@
+// micro-benchmark: peak VALU issue rate of non-packed f32 mul/add on gfx950 (for the roofline denominator)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+template <int MODE>
+__global__ void __launch_bounds__(256) k(float *out, int iters, float s)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll 8
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == 0) { a0 = a0 * s; a1 = a1 + s; a2 = a2 * s; a3 = a3 + s; a4 = a4 * s; a5 = a5 + s; a6 = a6 * s; a7 = a7 + s; }
+            if (MODE == 1) { a0 = __builtin_fmaf(a0, s, s); a1 = __builtin_fmaf(a1, s, s); a2 = __builtin_fmaf(a2, s, s); a3 = __builtin_fmaf(a3, s, s); a4 = __builtin_fmaf(a4, s, s); a5 = __builtin_fmaf(a5, s, s); a6 = __builtin_fmaf(a6, s, s); a7 = __builtin_fmaf(a7, s, s); }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+int main()
+{
+    float *d; hipMalloc(&d, 256 * 2048 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 2; ++mode)
+        for (int blocks : {256, 512, 1024, 2048}) {
+            const int iters = 20000;
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                if (mode == 0) k<0><<<blocks, 256>>>(d, iters, 1.0001f); else k<1><<<blocks, 256>>>(d, iters, 1.0001f);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+            }
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            double winstr = (double)blocks * 4 * iters * 64.0;   // wave-instructions
+            printf("mode %d blocks %d (%.1f waves/SIMD): %.3f ms  %.1f G wave-instr/s  = %.3f instr/cycle/SIMD @2.4GHz\n", mode, blocks, blocks * 4 / 1024.0, ms,
+                   winstr / ms / 1e6, winstr / (ms * 1e-3) / 1024 / 2.4e9);
+        }
+    return 0;
+}
