@@ -132,7 +132,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            except TypeError:          # a torch without the device_id argument: lazy communicator creation
+                dist.init_process_group(backend="nccl")
         else:
             dist.init_process_group(backend=backend)
 
