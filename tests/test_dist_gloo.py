@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, no_gather=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -31,6 +31,10 @@ def _worker(rank, world, port, out_path):
     from oracle import oracle
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if no_gather:          # a backend without gather: gather_frame must fall back to all_gather on every rank alike
+        def _refuse(*a, **k):
+            raise NotImplementedError("gather is not implemented by this backend")
+        dist.gather = _refuse
     render = load_render(scenes.cornell_box2(res=(40, 44), ssaa=1, sample=2))
     h = _abi.build_desc(render)
     o = oracle.Oracle(h, seed=4)
@@ -65,6 +69,29 @@ def test_two_rank_row_sharding_reassembles_the_frame(tmp_path, oracle_mod):
         p.start()
     for p in procs:
         p.join(180)
+        assert p.exitcode == 0
+    got = np.load(out)
+    h = _abi.build_desc(load_render(scenes.cornell_box2(res=(40, 44), ssaa=1, sample=2)))
+    o = oracle_mod.Oracle(h, seed=4)
+    o.execute(2)
+    assert np.array_equal(got, o.accum()[0])
+
+
+@pytest.mark.parametrize("world,no_gather", [(8, False), (3, True)])
+def test_more_ranks_uneven_shards_and_the_all_gather_fallback(tmp_path, oracle_mod, world, no_gather):
+    """8 ranks on a 44-row frame: six 8-row blocks, so two ranks own nothing but padding; and a backend that refuses
+    gather (3 ranks): rank 0 must still assemble the single-process frame bit for bit."""
+    import torch.multiprocessing as mp
+    from micro_raytracer_amd import _abi, load_render, scenes
+
+    out = str(tmp_path / "frame.npy")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, no_gather)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
         assert p.exitcode == 0
     got = np.load(out)
     h = _abi.build_desc(load_render(scenes.cornell_box2(res=(40, 44), ssaa=1, sample=2)))
