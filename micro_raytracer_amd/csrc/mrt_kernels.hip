@@ -31,7 +31,8 @@ constexpr bool lds_stash_for(bool scene_in_lds, int block_threads, u32 feat)
 #ifdef MRT_NO_STASH
     return false;
 #else
-    return scene_in_lds && block_threads != 512 && !(feat & F_NOSTASH);
+    (void)scene_in_lds;      // scenes read through L2 keep the stash too: the LDS is otherwise empty
+    return block_threads != 512 && !(feat & F_NOSTASH);
 #endif
 }
 constexpr int waves_for(u32 feat)
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         if constexpr (lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS, FEAT)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
             LdsStash<BLOCK_THREADS> st;
-            st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + ((P.lds_words + 3u) >> 2)) + threadIdx.x);
+            st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + (SCENE_IN_LDS ? ((P.lds_words + 3u) >> 2) : 0u)) + threadIdx.x);
             render_pixel<FEAT>(S, st, x, y, job, seg);
         } else {
             RegStash st;
@@ -233,8 +234,7 @@ static const LaunchFn kLds64[16] = MRT_ALL_FEATS(64);
 
 size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 features)
 {
-    if (!scene_in_lds) return 0;
-    size_t lds = (size_t)P.lds_words * 4u;
+    size_t lds = scene_in_lds ? (size_t)P.lds_words * 4u : 0u;
     if (lds_stash_for(scene_in_lds, (int)block_threads, features)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
     return lds;
 }
@@ -250,7 +250,7 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     }
     const size_t lds = pt_lds_bytes(P, block_threads, scene_in_lds, features);
     if (features & F_BVH) {         // many-instance scenes: one all-features + BVH instantiation per launch shape
-        if (!scene_in_lds) { if (block_threads != 256u) return hipErrorInvalidConfiguration; hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL | F_BVH>), grid, dim3(256), 0, stream, P, P.blob); }
+        if (!scene_in_lds) { if (block_threads != 256u) return hipErrorInvalidConfiguration; hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL | F_BVH>), grid, dim3(256), lds, stream, P, P.blob); }
         else if (block_threads == 64u) launch_lds<64, F_ALL | F_BVH>(grid, lds, stream, P);
         else if (block_threads == 256u) launch_lds<256, F_ALL | F_BVH>(grid, lds, stream, P);
         else if (block_threads == 512u) launch_lds<512, F_ALL | F_BVH>(grid, lds, stream, P);
@@ -268,7 +268,7 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
         else return hipErrorInvalidConfiguration;
     } else {
         if (block_threads != 256u) return hipErrorInvalidConfiguration;
-        hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL>), grid, dim3(256), 0, stream, P, P.blob);
+        hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL>), grid, dim3(256), lds, stream, P, P.blob);
     }
     return hipGetLastError();
 }
