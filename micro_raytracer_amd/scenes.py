@@ -76,6 +76,12 @@ def checker_texture(w=64, h=64, cell=8, a=(1.0, 1.0, 1.0), b=(40 / 255.0, 40 / 2
     return {"w": w, "h": h, "dat": dat}
 
 
+def floor_checker():
+    """The 64x64 floor texture of example/dof.json and example/Mesh.json as parameters: an 8-texel checker of
+    64/255 (top-left cell) and 150/255 greys (the asset carries +-3/255 of compression noise on top)."""
+    return checker_texture(64, 64, 8, a=(64 / 255.0,) * 3, b=(150 / 255.0,) * 3)
+
+
 def icosphere(subdiv=2, radius=0.45, squash=(1.5, 0.93, 1.08)):
     """Closed triangle mesh, 20 * 4^subdiv triangles (subdiv 2 -> 320, 3 -> 1280)."""
     t = (1.0 + math.sqrt(5.0)) / 2.0
@@ -129,7 +135,7 @@ def mesh_scene(res=(1920, 1080), ssaa=1, sample=256, bounce=8, n_tris=967, inlin
         "scene": {
             "renderer": [
                 {"type": "mesh", "mesh": mesh, "pos": [0, 0.5, 0], "mat": {"rough": 1}},
-                {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.5], "mat": {"rough": 1, "tex": checker_texture()}},
+                {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.5], "mat": {"rough": 1, "tex": floor_checker()}},
             ],
             "light": [{"type": "point", "pos": [-0.5, -1, 0.5], "pwr": 0.5, "color": "#ffffff"}],
         },
@@ -245,7 +251,7 @@ def dof_scene(res=(1280, 720), ssaa=1, sample=256, bounce=8):
                 {"type": "sphere", "r": 0.3, "mat": {"albedo": "#ee8c57"}},
                 {"type": "sphere", "r": 0.3, "pos": [-1.125, 1.25, 0], "mat": {"metal": 1}},
                 {"type": "box", "sizes": [0.6, 0.6, 0.6], "pos": [1.125, 1.25, 0], "mat": {"rough": 1, "albedo": "#f7a3d7"}},
-                {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.3], "mat": {"rough": 1, "tex": checker_texture()}},
+                {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.3], "mat": {"rough": 1, "tex": floor_checker()}},
             ],
             "light": [{"type": "point", "pos": [-0.5, -1, 0.5], "pwr": 0.5, "color": "#ffffff"}],
         },

@@ -1,4 +1,4 @@
-"""Derive small pin fixtures from the rendered images the reference ships (doc/out0..3.png).
+"""Derive small pin fixtures from the rendered images the reference ships (doc/out0..4.png).
 
 Run here (the reference checkout is not present on the GPU box):
     python tests/golden/make_doc_pins.py /root/reference
@@ -14,6 +14,9 @@ source text:
                    inverse-tone-mapped linear radiance averaged over 8x8 blocks centred on
                    (8x, 8y) + a validity mask (no saturated u8 in the block).  statistical pin
   out3_blocks.npz  doc/out3.png (README.md:16-27, CornellBox2 geometry, 1080x1080 ssaa 2) same.
+  out4_blocks.npz  doc/out4.png (README.md:11, = example/dof.json, 1280x720, default gamma 0.8 / exp 0.2) same:
+                   plane-UV texture lookup, thin-lens DoF with a real aperture, the rolled camera
+                   (rotate_y), box + spheres under a point light with shadows.  statistical pin
 """
 import os
 import sys
@@ -61,6 +64,8 @@ def main(ref_root):
     np.savez_compressed(os.path.join(HERE, "out2_blocks.npz"), f=8, lin=b, ok=ok)
     b, ok = blocks(os.path.join(doc, "out3.png"), 8, 0.6, 0.8)
     np.savez_compressed(os.path.join(HERE, "out3_blocks.npz"), f=8, lin=b, ok=ok)
+    b, ok = blocks(os.path.join(doc, "out4.png"), 8, 0.8, 0.2)
+    np.savez_compressed(os.path.join(HERE, "out4_blocks.npz"), f=8, lin=b, ok=ok)
 
 
 if __name__ == "__main__":

@@ -68,6 +68,32 @@ def test_c3_cornellbox2_3840x2160_ssaa2_shards_and_band_parity(oracle_mod):
     assert np.array_equal(img, oracle_mod.lanczos3_resize(s.img_ss(), 1920, 1080))
 
 
+def test_c4_cornellbox2_3840x2160_ssaa1_shards_and_band_parity(oracle_mod):
+    """BASELINE.json configs[3] as described: CornellBox2 at res 3840x2160, ssaa 1 (no resize in img), bounce 16,
+    row-sharded 8 ways (block-cyclic, the partition the 8-GPU run uses): shards reassemble the single-context frame
+    bit for bit, oracle parity on a band, and img == the tone-mapped frame (image 0.24 copies when sizes match)."""
+    from micro_raytracer_amd import scenes
+    render, holder = make_holder(scenes.cornell_box2(res=(3840, 2160), ssaa=1, sample=2, bounce=16))
+    s = _render(render, 2)
+    a, _ = s.accum()
+    assert a.shape == (2160, 3840, 3)
+    whole = np.zeros_like(a)
+    for r in range(8):
+        loc, rows = _render(render, 2, shard_index=r, shard_count=8).accum_local()
+        whole[rows] = loc
+    assert np.array_equal(a, whole)
+    o = oracle_mod.Oracle(holder, seed=9)
+    o.execute(2, rows=(1080, 1084))
+    ref, _ = o.accum()
+    err = np.abs(a[1080:1084] - ref[1080:1084]).max() / 2
+    print(f"C4 band L-inf {err:.3e}")
+    assert err <= 1e-4
+    img = s.img()
+    assert img.shape == (2160, 3840, 3) and np.array_equal(img, s.img_ss())
+    o.set_accum(a, 2)
+    assert np.array_equal(img[1080:1084], o.img()[1080:1084])
+
+
 def test_c5_mesh_and_minecraft_shapes_band_parity(oracle_mod):
     """BASELINE.json configs[4]: triangle-heavy / textured scenes at 1920x1080 (1 spp), parity on a band."""
     from micro_raytracer_amd import scenes

@@ -1,7 +1,7 @@
 """Pin the CPU oracle against the only result artefacts the reference holds: its README renders.
 
 The reference has no tests, no golden vectors and no RNG seed; tests/golden/*.npz are sub-sampled
-pixels / block means of doc/out0..3.png (tests/golden/make_doc_pins.py).  out0 / out1 are
+pixels / block means of doc/out0..4.png (tests/golden/make_doc_pins.py).  out0 / out1 are
 deterministic up to a +-0.0005 lens jitter on the sphere silhouette; out2 / out3 are statistical.
 """
 import os
@@ -43,7 +43,7 @@ def test_out1_ssaa2_lanczos_pin(oracle_mod):
 def _stat_pin(oracle_mod, desc, pin, spp, sb):
     _, h = make_holder(desc)
     o = oracle_mod.Oracle(h, seed=3)
-    o.execute(spp)
+    o.execute(spp, threads=min(8, os.cpu_count() or 1))      # counter RNG: the result does not depend on the thread count
     acc, cnt = o.accum()
     mean = acc / cnt
     ref, ok = pin["lin"], pin["ok"] & (pin["lin"].min(axis=2) > 1e-3)
@@ -67,9 +67,11 @@ def test_out2_cornell_box_statistical_pin(oracle_mod):
     from micro_raytracer_amd import scenes
     pin = np.load(os.path.join(G, "out2_blocks.npz"))
     f = int(pin["f"])
-    ratio, errs = _stat_pin(oracle_mod, scenes.cornell_box(res=(1280 // f, 720 // f), sample=1024, bounce=16, floor_z=-0.201), pin, 192, 10)
-    assert abs(ratio - 1.0) < 0.03, ratio
-    assert np.median(errs) < 0.08, np.median(errs)
+    # SURVEY.md App. C acceptance: global linear mean within 2 %, median block error <= 2 % (measured 0.06 % / 1.4 %;
+    # the block error is noise-limited: 4.9 % at 192 spp, 2.3 % at 1024, 1.4 % at 2048)
+    ratio, errs = _stat_pin(oracle_mod, scenes.cornell_box(res=(1280 // f, 720 // f), sample=1024, bounce=16, floor_z=-0.201), pin, 2048, 10)
+    assert abs(ratio - 1.0) <= 0.02, ratio
+    assert np.median(errs) <= 0.02, np.median(errs)
 
 
 def test_out3_cornell_box2_statistical_pin(oracle_mod):
@@ -77,6 +79,20 @@ def test_out3_cornell_box2_statistical_pin(oracle_mod):
     from micro_raytracer_amd import scenes
     pin = np.load(os.path.join(G, "out3_blocks.npz"))
     f = int(pin["f"])
-    ratio, errs = _stat_pin(oracle_mod, scenes.cornell_box2(res=(1080 // f, 1080 // f), ssaa=1, sample=1024, bounce=8), pin, 192, 9)
-    assert abs(ratio - 1.0) < 0.04, ratio
-    assert np.median(errs) < 0.08, np.median(errs)
+    ratio, errs = _stat_pin(oracle_mod, scenes.cornell_box2(res=(1080 // f, 1080 // f), ssaa=1, sample=1024, bounce=8), pin, 2048, 9)
+    assert abs(ratio - 1.0) <= 0.02, ratio           # measured -1.2 %
+    assert np.median(errs) <= 0.02, np.median(errs)  # measured 1.4 %
+
+
+def test_out4_dof_scene_pin(oracle_mod):
+    """doc/out4.png (README.md:11) == example/dof.json at its defaults (1280x720, gamma 0.8, exp 0.2): the only
+    reference output with plane-UV texture lookup (src/rt.rs:528-542, 618-628), thin-lens DoF with a real aperture
+    (src/rt.rs:916-922), the rolled camera (rotate_y, src/lin.rs:175-183) and box + spheres under a point light with
+    shadows (src/rt.rs:1027-1046).  The floor texture is regenerated from its parameters (scenes.floor_checker)."""
+    from micro_raytracer_amd import scenes
+    pin = np.load(os.path.join(G, "out4_blocks.npz"))
+    f = int(pin["f"])
+    ratio, errs = _stat_pin(oracle_mod, scenes.dof_scene(res=(1280 // f, 720 // f), sample=512), pin, 512, 10)
+    assert abs(ratio - 1.0) <= 0.01, ratio           # measured +0.19 %
+    assert np.median(errs) <= 0.015, np.median(errs) # measured 0.41 %
+    assert np.percentile(errs, 95) <= 0.04, np.percentile(errs, 95)   # measured 1.1 %
