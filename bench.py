@@ -30,6 +30,9 @@ FLOP_PER_SEGMENT = 400.0       # SURVEY.md §8d algorithmic estimate for the Cor
 WORKLOADS = {
     # name: (builder kwargs, spp per step)
     "cornell_1080p_1024spp_b8": (dict(kind="cornell_box", res=(1920, 1080), bounce=8), 1024),
+    # the same frame driven the way the reference's unmodified callers drive the boundary: one Sampler::execute per sample
+    # (src/cli.rs:162-170, src/http.rs:141-144) = 1024 x mrt_execute(ctx, 1) per step
+    "cornell_1080p_percall": (dict(kind="cornell_box", res=(1920, 1080), bounce=8), 1024),
     "cornell_512_64spp_b8": (dict(kind="cornell_box", res=(512, 512), bounce=8), 64),           # BASELINE.json configs[1]
     "cornell2_4k_64spp_b16": (dict(kind="cornell_box2", res=(1920, 1080), ssaa=2, bounce=16), 64),  # configs[2] geometry
     # the BASELINE.json configs at their full sizes (one step = the whole render)
@@ -71,6 +74,7 @@ def cpu_baseline(render, seconds_target=12.0):
 
 
 VALU_ISSUE_PEAK_GINSTR = 1171.0   # G wave-instructions/s of independent v_mul/v_add/v_fma measured on MI355X
+VALU_ISSUE_ARCH_GINSTR = 1228.8   # architectural: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction
 
 
 def pmc_profile(workload, world):
@@ -113,6 +117,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves.  The parent has made no GPU call (torch is not
+        # even imported yet), so the children are fresh processes; rank 0's JSON line goes straight to our stdout and
+        # the exit code is the launcher's (non-zero if any rank failed).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     import torch
     import torch.distributed as dist
 
@@ -120,7 +138,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the backend has no CPU path)")
     # MRT_DIST_BACKEND=gloo + MRT_SHARE_DEVICE=1 rehearse the N > 1 path on a one-GPU box (all ranks on device 0,
@@ -145,7 +163,7 @@ def main():
     if args.spp:
         spp = args.spp
     render = build_render(spec, spp)
-    ss = ShardedSampler(render, rank, world, local_rank, seed=1)
+    ss = ShardedSampler(render, rank, world, local_rank, seed=1, flags=1)     # MRT_FLAG_COUNT_SEGMENTS: the VALU model needs segments
     nw, nh = ss.nw, ss.nh
 
     def sync():
@@ -154,18 +172,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    percall = args.workload.endswith("_percall")
+
+    def step():
+        """One step.  Batched: one mrt_execute(ctx, spp).  Per call: spp x mrt_execute(ctx, 1), each synchronous like
+        the scoped-pool join of src/sampler.rs:39-74, gathered once at the end of the step; returns (kernel ms, segments)."""
+        if not percall:
+            ss.execute(spp)
+            st = ss.s.stats()
+            return st["kernel_ms"], st["segments"]
+        for i in range(spp):
+            ss.execute(1, gather=(i == spp - 1))
+        st = ss.s.stats()                       # stats of the LAST call only: the per-call path reads nothing back per call
+        return st["kernel_ms"] * spp, st["segments"] * spp
+
     for _ in range(args.warmup):
-        ss.execute(spp)
+        step()
     sync()
-    kernel_ms, segments = [], 0
+    kernel_ms, gather_ms, segments = [], [], 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ss.execute(spp)
-        st = ss.s.stats()
-        kernel_ms.append(st["kernel_ms"])
-        segments += st["segments"]
+        k, sg = step()
+        kernel_ms.append(k)
+        gather_ms.append(ss.last_gather_ms)
+        segments += sg
     sync()
     elapsed = time.perf_counter() - t0
+    k_mean = sum(kernel_ms) / max(1, len(kernel_ms))
+    k_min = k_max = k_mean
     if world > 1:
         red_dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -174,6 +208,9 @@ def main():
         seg_t = torch.tensor([float(segments)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
         total_segments = float(seg_t.item())
+        km = torch.tensor([k_mean, -k_mean], dtype=torch.float64, device=red_dev)      # per-rank kernel time: max and min
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        k_max, k_min = float(km[0].item()), -float(km[1].item())
     else:
         total_segments = float(segments)
 
@@ -184,11 +221,16 @@ def main():
         # = accumulator read + write (12 B + 12 B per owned pixel) + one read of the packed scene
         px_local = ss.s.local_rows * nw
         alg_bytes = 24.0 * px_local + st["scene_bytes"]
-        if st["k_split"] > 1:          # sample split: pt_megakernel writes one f32x3 chunk sum per pixel per 16 samples (reduce_chunks,
+        alg_bytes_8d = alg_bytes
+        if percall:
+            pass                                 # every pass is a launch: 24 B per pixel + the scene, per launch
+        elif st["k_split"] > 1:          # sample split: pt_megakernel writes one f32x3 chunk sum per pixel per 16 samples (reduce_chunks,
             alg_bytes = 12.0 * px_local * ((spp + 15) // 16) + st["scene_bytes"]     # timed apart, folds them into the accumulator)
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        if percall:
+            k_ms /= spp                          # per launch (estimated from the last call of each step)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        seg_local = segments / max(1, args.steps)
+        seg_local = segments / max(1, args.steps) / (spp if percall else 1)
         valu_tflops = seg_local * FLOP_PER_SEGMENT / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         line = {
             "metric": "Msamples/sec (res x spp)", "value": samples / elapsed / 1e6, "unit": "Msamples/s",
@@ -197,10 +239,16 @@ def main():
             "config": {"workload": args.workload, "scene": spec["kind"],
                        "res": [render.frame.res[0], render.frame.res[1]], "ssaa": render.frame.ssaa, "spp_per_step": spp,
                        "bounce": render.rt.bounce, "samples_per_step": float(nw) * nh * spp,
+                       "calls_per_step": spp if percall else 1,
                        "sharding": f"rows, block-cyclic x{ss.shard_rows}, {world} rank(s), 1 RCCL gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # the bound that binds (neither HBM nor MFMA): FP32 VALU issue and lane utilisation
+                         "algorithmic_bytes_8d": alg_bytes_8d, "valu_model_frac": valu_tflops / VALU_PEAK_TFLOPS,
+                         "valu_issue_frac": None, "lane_utilisation": None,
                          "traffic": (pmc_traffic(args.workload, world) or (None, None))[0] if not args.spp else None,
                          "traffic_source": (pmc_traffic(args.workload, world) or (None, None))[1] if not args.spp else None, "kernel": "pt_megakernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms_rank_min": k_min, "kernel_ms_rank_max": k_max,
+                         "gather_ms": sum(gather_ms) / max(1, len(gather_ms)) if world > 1 else 0.0,
                          "note": "by construction not HBM-bound (SURVEY.md §8d): the scene lives in LDS, HBM sees 24 B per pixel per launch, or with sample split one 12 B chunk sum per pixel per 16 samples, which reduce_chunks (reduce_ms) then folds into the accumulator; kernel_ms is pt_megakernel alone", "reduce_ms": st.get("reduce_ms")},
             "valu": {"achieved_tflops": valu_tflops, "peak_tflops": VALU_PEAK_TFLOPS, "frac": valu_tflops / VALU_PEAK_TFLOPS,
                      "segments_per_sample": total_segments / samples, "flop_per_segment_model": FLOP_PER_SEGMENT,
@@ -218,6 +266,9 @@ def main():
             dv, ms = prof[0]["derived"], prof[0].get("avg_ms", 0.0)
             if ms > 0:
                 g = dv["valu_wave_instr"] / (ms * 1e-3) / 1e9
+                line["roofline"]["valu_issue_frac"] = g / VALU_ISSUE_ARCH_GINSTR
+                line["roofline"]["lane_utilisation"] = dv.get("lane_utilisation")
+                line["roofline"]["valu_pmc_source"] = prof[1]
                 line["valu"]["pmc"] = {"source": prof[1], "valu_wave_instr_per_launch": dv["valu_wave_instr"], "kernel_ms": ms,
                                        "G_wave_instr_per_s": g, "frac_of_measured_issue_peak": g / VALU_ISSUE_PEAK_GINSTR,
                                        "lane_utilisation": dv.get("lane_utilisation"),

@@ -39,6 +39,15 @@ int fail(int code, const char *fmt, ...)
 }
 void ok() { g_status = MRT_OK; }
 
+// A HIP call whose failure is tolerated: HIP 7 keeps the last *real* error pending (hipGetLastError no longer reports the
+// last call's status), so the pending error is cleared here or the next launch's hipGetLastError() would report it.
+bool hip_tolerated(hipError_t e)
+{
+    if (e == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
         hipError_t e_ = (expr);                                                                                \
@@ -84,13 +93,22 @@ constexpr size_t kSmallScene = 6u * 1024u;          // <= this: single-wave work
 // differ in path length).  Measured on the 1080p x 1024 spp Cornell box (tests/gpu_shard_probe.py): whole frame 328 -> 315 ms
 // with 4 lanes per pixel, one shard of 8 GPUs 47.1 -> 42.4 ms with 16.
 constexpr unsigned long long kSplitTargetWaves = 120000ull;
+// A sample-split launch writes one f32x3 chunk sum per pixel per 16 samples; the buffer is bounded by cutting one
+// mrt_execute into several launches of at most this many sample chunks (1024 samples) and this many bytes.  Launch
+// boundaries are chunk boundaries, so the canonical accumulation order -- and every bit -- is unchanged.
+constexpr u32 kMaxChunksPerLaunch = 64u;
+constexpr size_t kPartialBudgetBytes = (size_t)4u << 30;
 
 }  // namespace
 
 struct mrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // img timing
+    std::vector<hipEvent_t> evs;                  // 3 per launch of the last execute: start, after pt_megakernel, after reduce_chunks
+    u32 ev_used = 0;
+    bool stats_pending = false;                   // event times / segment counter of the last execute not read back yet
+    bool count_segments = false;                  // MRT_FLAG_COUNT_SEGMENTS
     Packed pk;
     Params P;
     u32 *d_blob = nullptr;
@@ -143,12 +161,16 @@ void free_ctx(mrt_ctx *c)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->evm) (void)hipEventDestroy(c->evm);
+    for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 }  // namespace
+
+// error text / status setter for the other translation units of the library (mrt_image_io.cpp)
+int mrt_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
+void mrt_internal_ok() { ok(); }
 
 extern "C" {
 
@@ -198,7 +220,6 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
-    if ((e = hipEventCreate(&c->evm)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipEventCreate", e);
     const size_t all_bytes = (size_t)c->pk.blob.size() * 4;
     if ((e = hipMalloc((void **)&c->d_blob, all_bytes ? all_bytes : 16)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
     if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), all_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
@@ -254,14 +275,15 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         // persistent launches (workgroups of more than one wavefront): as many workgroups as fit the device at once; each
         // wavefront then draws 8x8 tiles from a counter, so no CU waits for the slowest wavefront of a workgroup
         int n_cu = 0;
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n_cu <= 0) n_cu = 256;
+        if (!hip_tolerated(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device)) || n_cu <= 0) n_cu = 256;
         const size_t lds = pt_lds_bytes(c->pk.P, c->block_threads, c->scene_in_lds, c->pk.features);
         size_t per_cu = 32u / (c->block_threads / 64u);
         if (lds && kLdsLimit / lds < per_cu) per_cu = kLdsLimit / lds;
         if (per_cu < 1u) per_cu = 1u;
         c->P.persist_grid = c->block_threads > 64u && !getenv("MRT_NO_PERSIST") ? (u32)(n_cu * per_cu) : 0u;
     }
-    c->P.count_segments = 1;
+    c->count_segments = (opts->flags & MRT_FLAG_COUNT_SEGMENTS) != 0;
+    c->P.count_segments = c->count_segments ? 1u : 0u;
     memset(&c->stats, 0, sizeof c->stats);
     c->stats.lds_bytes = (u32)pt_lds_bytes(c->pk.P, c->block_threads, c->scene_in_lds, c->pk.features);
     c->stats.block_threads = c->block_threads;
@@ -335,41 +357,97 @@ mrt_ctx *mrt_create(const mrt_render_desc *desc, const mrt_opts *opts)
 
 void mrt_destroy(mrt_ctx *ctx) { free_ctx(ctx); }
 
+// Lazy half of the per-execute statistics: HIP-event times and (MRT_FLAG_COUNT_SEGMENTS) the segment counter are read
+// back when somebody asks (mrt_get_stats), not on every mrt_execute -- the reference's callers run one pass per call
+// (src/cli.rs:162-170), so the per-call cost is what the drop-in binary pays 1024 times per frame.
+static int resolve_stats(mrt_ctx *c)
+{
+    if (!c->stats_pending) return MRT_OK;
+    c->stats_pending = false;
+    int rc = set_device(c);
+    if (rc) return rc;
+    double k = 0, r = 0;
+    for (u32 i = 0; i + 2u < c->ev_used; i += 3u) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, c->evs[i], c->evs[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, c->evs[i + 1], c->evs[i + 2]));
+        k += a; r += b;
+    }
+    c->stats.kernel_ms = k;
+    c->stats.reduce_ms = c->stats.k_split > 1u ? r : 0.0;
+    if (c->count_segments) {
+        unsigned long long seg = 0;
+        HIP_TRY(hipMemcpy(&seg, c->d_segments, sizeof seg, hipMemcpyDeviceToHost));
+        c->stats.segments = seg;
+    }
+    return MRT_OK;
+}
+
 // asynchronous half of mrt_execute on one device: everything up to the closing event
 static int exec_launch(mrt_ctx *c, uint32_t n_samples)
 {
     int rc = set_device(c);
     if (rc) return rc;
     c->stats.kernel_ms = 0; c->stats.reduce_ms = 0; c->stats.gather_ms = 0; c->stats.launches = 0; c->stats.samples = 0; c->stats.segments = 0;
+    c->stats_pending = false; c->ev_used = 0;
     if (!(n_samples && c->local_rows)) return MRT_OK;
-    HIP_TRY(hipMemsetAsync(c->d_segments, 0, 2 * sizeof(unsigned long long), c->stream));
-    c->P.n_samples = n_samples;
-    c->P.sample_base = c->count;
+    if (c->count_segments) HIP_TRY(hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
+    const bool persist = c->block_threads > 64u && c->P.persist_grid != 0u;
     // sample split: spread a small frame over more wavefronts, one lane per (pixel, every k-th sample chunk)
-    const u32 g0 = c->count / kChunk;
-    const u32 n_chunks = (c->count + n_samples - 1u) / kChunk - g0 + 1u;
+    const u32 first_chunk = c->count / kChunk;
+    const u32 end_chunk = (c->count + n_samples - 1u) / kChunk + 1u;
+    const u32 n_chunks = end_chunk - first_chunk;
     const unsigned long long wave_tiles = (unsigned long long)((c->pk.nw + 7) / 8) * ((c->local_rows + 7) / 8);
     u32 k_split = 1;
     while (k_split * 2u <= n_chunks && k_split < 16u && wave_tiles * k_split < kSplitTargetWaves) k_split *= 2u;
     if (const char *f = getenv("MRT_K_SPLIT")) { k_split = (u32)atoi(f); if (k_split < 1u) k_split = 1u; while (k_split > n_chunks) k_split /= 2u; }
     const size_t plane = (size_t)c->padded_rows * c->pk.nw * 3;
+    u32 cap = kMaxChunksPerLaunch;                       // chunks per launch
+    if (const char *f = getenv("MRT_MAX_CHUNKS")) { const int v = atoi(f); if (v > 0) cap = (u32)v; }        // tests
+    size_t budget = kPartialBudgetBytes;
+    if (const char *f = getenv("MRT_PARTIAL_LIMIT_BYTES")) budget = (size_t)strtoull(f, nullptr, 10);         // tests
     if (k_split > 1u) {
-        const size_t need = plane * n_chunks;
-        if (need > c->partial_floats) {
+        if (cap < k_split) cap = k_split;
+        while (cap > k_split && plane * cap * sizeof(float) > budget) cap /= 2u;
+        const size_t need = plane * (n_chunks < cap ? n_chunks : cap);
+        if (need * sizeof(float) > budget) k_split = 1u;                       // not even k_split planes fit: one lane per pixel
+        else if (need > c->partial_floats) {
             if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_floats = 0; }
-            if (hipMalloc((void **)&c->d_partial, need * sizeof(float)) != hipSuccess) k_split = 1u;    // fall back to one lane per pixel
+            const size_t ask = getenv("MRT_PARTIAL_FAIL_ALLOC") ? ((size_t)1 << 60) : need * sizeof(float);      // tests: an impossible size
+            if (!hip_tolerated(hipMalloc((void **)&c->d_partial, ask))) { c->d_partial = nullptr; k_split = 1u; }
             else c->partial_floats = need;
         }
     }
-    c->P.k_split = k_split;
     c->P.partial = c->d_partial;
     c->P.partial_stride = plane;
     c->stats.k_split = k_split;
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
-    HIP_TRY(hipEventRecord(c->evm, c->stream));
-    if (k_split > 1u) HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_partial, (size_t)c->local_rows * c->pk.nw * 3, plane, n_chunks, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    const u32 s_end = c->count + n_samples;
+    u32 base = c->count;
+    while (base < s_end) {
+        // this launch: samples [base, stop), stop on a chunk boundary (or the end); k_split == 1 needs no buffer: one launch
+        u32 stop = s_end;
+        if (k_split > 1u) {
+            const unsigned long long lim = ((unsigned long long)(base / kChunk) + cap) * kChunk;
+            if (lim < stop) stop = (u32)lim;
+        }
+        const u32 nc = (stop - 1u) / kChunk - base / kChunk + 1u;
+        u32 ks = k_split;
+        while (ks > nc) ks /= 2u;
+        c->P.n_samples = stop - base;
+        c->P.sample_base = base;
+        c->P.k_split = ks;
+        while (c->evs.size() < (size_t)c->ev_used + 3u) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->evs.push_back(e); }
+        hipEvent_t *ev = &c->evs[c->ev_used];
+        if (persist) HIP_TRY(hipMemsetAsync(c->P.tile_counter, 0, sizeof(u32), c->stream));
+        HIP_TRY(hipEventRecord(ev[0], c->stream));
+        HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
+        HIP_TRY(hipEventRecord(ev[1], c->stream));
+        if (ks > 1u) HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_partial, (size_t)c->local_rows * c->pk.nw * 3, plane, nc, c->stream));
+        HIP_TRY(hipEventRecord(ev[2], c->stream));
+        c->ev_used += 3u;
+        c->stats.launches += 1u;
+        base = stop;
+    }
     return MRT_OK;
 }
 
@@ -379,15 +457,8 @@ static int exec_finish(mrt_ctx *c, uint32_t n_samples)
     if (rc) return rc;
     if (n_samples && c->local_rows) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        float ms = 0;
-        float red = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->evm));
-        HIP_TRY(hipEventElapsedTime(&red, c->evm, c->ev1));
-        c->stats.reduce_ms = c->stats.k_split > 1u ? red : 0.0;
-        unsigned long long seg = 0;
-        HIP_TRY(hipMemcpy(&seg, c->d_segments, sizeof seg, hipMemcpyDeviceToHost));
-        c->stats.kernel_ms = ms; c->stats.launches = 1; c->stats.segments = seg;
         c->stats.samples = (uint64_t)c->local_rows * c->pk.nw * n_samples;
+        c->stats_pending = true;
     }
     c->count += n_samples;                                        // src/sampler.rs:76
     return MRT_OK;
@@ -396,20 +467,33 @@ static int exec_finish(mrt_ctx *c, uint32_t n_samples)
 static int exec_group(mrt_ctx *g, uint32_t n_samples)
 {
     const u32 n = (u32)g->subs.size();
-    int rc;
-    for (mrt_ctx *s : g->subs) if ((rc = exec_launch(s, n_samples))) return rc;
+    int rc = MRT_OK;
+    u32 launched = 0;
+    for (; launched < n; ++launched) if ((rc = exec_launch(g->subs[launched], n_samples))) break;
+    // an error from here on still waits for everything that was launched, so no kernel is left running on a buffer
+    // the caller may free; the first error is the one reported
+    auto drain = [&](u32 upto) { for (u32 r = 0; r < upto; ++r) { if (hipSetDevice(g->subs[r]->device) == hipSuccess) (void)hipStreamSynchronize(g->subs[r]->stream); } (void)hipGetLastError(); };
+    if (rc) { const std::string keep = g_err; drain(launched + (launched < n ? 1u : 0u)); g_err = keep; g_status = rc; return rc; }
     // one gather per batch: rank r sends its padded shard accumulator, device 0 receives rank i at offset i * plane
     const auto tg = std::chrono::steady_clock::now();
     const size_t plane = (size_t)g->subs[0]->padded_rows * g->pk.nw * 3;
     int nrc = g_rccl.GroupStart();
-    for (u32 r = 0; r < n && nrc == 0; ++r) {
-        HIP_TRY(hipSetDevice((int)r));
-        nrc = g_rccl.Gather(g->subs[r]->d_accum, r == 0 ? g->d_gather : nullptr, plane, kNcclFloat, 0, g->comms[r], g->subs[r]->stream);
+    hipError_t he = hipSuccess;
+    if (nrc == 0) {
+        for (u32 r = 0; r < n && nrc == 0 && he == hipSuccess; ++r) {
+            if ((he = hipSetDevice(g->subs[r]->device)) != hipSuccess) break;
+            nrc = g_rccl.Gather(g->subs[r]->d_accum, r == 0 ? g->d_gather : nullptr, plane, kNcclFloat, 0, g->comms[r], g->subs[r]->stream);
+        }
+        const int nrc2 = g_rccl.GroupEnd();                         // always closed, whatever happened inside the group
+        if (nrc == 0) nrc = nrc2;
     }
-    const int nrc2 = g_rccl.GroupEnd();
-    if (nrc != 0 || nrc2 != 0) return fail(MRT_ERR_DEVICE, "ncclGather: %s", g_rccl.GetErrorString(nrc ? nrc : nrc2));
-    for (mrt_ctx *s : g->subs) if ((rc = exec_finish(s, n_samples))) return rc;    // syncs every stream (kernel + gather)
-    HIP_TRY(hipSetDevice(0));
+    if (he != hipSuccess || nrc != 0) {
+        drain(n);
+        if (he != hipSuccess) return fail(MRT_ERR_DEVICE, "hipSetDevice failed inside the gather group: %s", hipGetErrorString(he));
+        return fail(MRT_ERR_DEVICE, "ncclGather: %s", g_rccl.GetErrorString(nrc));
+    }
+    for (mrt_ctx *s : g->subs) if ((rc = exec_finish(s, n_samples))) { const std::string keep = g_err; drain(n); g_err = keep; g_status = rc; return rc; }    // syncs every stream (kernel + gather)
+    HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(launch_scatter_rows(g->d_full, g->d_gather, g->d_rowmap, n * g->subs[0]->padded_rows, g->pk.nw * 3u, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     g->count += n_samples;
@@ -417,6 +501,7 @@ static int exec_group(mrt_ctx *g, uint32_t n_samples)
     memset(&g->stats, 0, offsetof(mrt_stats, lds_bytes));
     g->stats.reduce_ms = 0;
     for (mrt_ctx *s : g->subs) {
+        if ((rc = resolve_stats(s))) return rc;
         if (s->stats.kernel_ms > g->stats.kernel_ms) g->stats.kernel_ms = s->stats.kernel_ms;
         if (s->stats.reduce_ms > g->stats.reduce_ms) g->stats.reduce_ms = s->stats.reduce_ms;
         g->stats.samples += s->stats.samples; g->stats.segments += s->stats.segments; g->stats.launches += s->stats.launches;
@@ -680,6 +765,7 @@ int mrt_img(mrt_ctx *c, uint8_t *rgb8)
 int mrt_get_stats(const mrt_ctx *c, mrt_stats *out)
 {
     if (!c || !out) return fail(MRT_ERR_ARG, "mrt_get_stats: null argument");
+    if (c->stats_pending) { const int rc = resolve_stats(const_cast<mrt_ctx *>(c)); if (rc) return rc; }
     *out = c->stats;
     ok();
     return MRT_OK;
@@ -692,17 +778,24 @@ int mrt_selftest_math(int device, int op, const float *a, const float *b, float 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MRT_ERR_DEVICE, "mrt_selftest_math: no HIP device");
     if (device < 0) device = 0;
     HIP_TRY(hipSetDevice(device));
+    if (n == 0) { ok(); return MRT_OK; }
     float *da = nullptr, *db = nullptr, *dout = nullptr;
     const size_t bytes = n * sizeof(float);
-    if (n == 0) { ok(); return MRT_OK; }
-    HIP_TRY(hipMalloc((void **)&da, bytes));
-    HIP_TRY(hipMalloc((void **)&dout, bytes));
-    HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-    if (b) { HIP_TRY(hipMalloc((void **)&db, bytes)); HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
-    HIP_TRY(launch_math_selftest(op, da, db, dout, n, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    auto run = [&]() -> int {                 // every exit goes through the frees below
+        HIP_TRY(hipMalloc((void **)&da, bytes));
+        HIP_TRY(hipMalloc((void **)&dout, bytes));
+        HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+        if (b) { HIP_TRY(hipMalloc((void **)&db, bytes)); HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
+        HIP_TRY(launch_math_selftest(op, da, db, dout, n, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+        return MRT_OK;
+    };
+    const int rc = run();
+    if (da) (void)hipFree(da);
+    if (dout) (void)hipFree(dout);
+    if (db) (void)hipFree(db);
+    if (rc) return rc;
     ok();
     return MRT_OK;
 }

@@ -8,9 +8,16 @@
 #include <string>
 #include <vector>
 
+#include <errno.h>
+
 #include "../../include/mrt.h"
 
+int mrt_internal_fail(int code, const char *msg);     // mrt_api.cpp: sets mrt_last_error / mrt_last_status
+void mrt_internal_ok();
+
 namespace {
+
+int failf(int code, const std::string &msg) { return mrt_internal_fail(code, msg.c_str()); }
 
 struct CrcTable {
     uint32_t t[256];
@@ -36,7 +43,10 @@ void chunk(std::vector<uint8_t> &out, const char *type, const std::vector<uint8_
 
 extern "C" int mrt_save_image(const char *path, const uint8_t *rgb8, uint32_t w, uint32_t h)
 {
-    if (!path || !rgb8 || !w || !h) return MRT_ERR_ARG;
+    if (!path || !rgb8 || !w || !h) return failf(MRT_ERR_ARG, "mrt_save_image: null path / pixels or empty image");
+    // one IDAT chunk with a 32-bit length (and the 32-bit sizes of PPM readers): refuse what cannot be represented
+    if ((unsigned long long)h * ((unsigned long long)w * 3u + 1u) > 0x7ff00000ull)
+        return failf(MRT_ERR_LIMIT, "mrt_save_image: " + std::to_string(w) + "x" + std::to_string(h) + " exceeds the 2 GiB limit of this writer");
     const char *dot = strrchr(path, '.');
     const std::string ext = dot ? dot + 1 : "";
     std::vector<uint8_t> out;
@@ -70,11 +80,13 @@ extern "C" int mrt_save_image(const char *path, const uint8_t *rgb8, uint32_t w,
         chunk(out, "IDAT", z);
         chunk(out, "IEND", {});
     } else {
-        return MRT_ERR_ARG;
+        return failf(MRT_ERR_ARG, std::string("mrt_save_image: unsupported extension in '") + path + "' (.ppm and .png are written)");
     }
     FILE *f = fopen(path, "wb");
-    if (!f) return MRT_ERR_STATE;
+    if (!f) return failf(MRT_ERR_STATE, std::string("mrt_save_image: cannot open '") + path + "': " + strerror(errno));
     const size_t wr = fwrite(out.data(), 1, out.size(), f);
-    fclose(f);
-    return wr == out.size() ? MRT_OK : MRT_ERR_STATE;
+    const int werr = errno;
+    if (fclose(f) != 0 || wr != out.size()) return failf(MRT_ERR_STATE, std::string("mrt_save_image: short write to '") + path + "': " + strerror(werr ? werr : errno));
+    mrt_internal_ok();
+    return MRT_OK;
 }

@@ -31,9 +31,37 @@ def padded_rows(nh: int, world: int, shard_rows: int = DEFAULT_SHARD_ROWS) -> in
     return ((n_blocks + world - 1) // world) * shard_rows
 
 
-def gather_frame(local, nh: int, nw: int, shard_rows: int = DEFAULT_SHARD_ROWS, dst: int = 0, group=None, out=None):
+def probe_gather(device=None, group=None) -> bool:
+    """Decide ONCE, on every rank alike, whether this backend build offers `gather`; returns True when all_gather has
+    to stand in for it.  A build without the op raises before anything is sent, on every rank (NotImplementedError /
+    "not supported" RuntimeError); the ranks then agree on the answer with one all_reduce.  Called once per
+    ShardedSampler: later failures of a collective are real failures and propagate."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    staged = device is not None and dist.get_backend(group) != "nccl"
+    t = torch.zeros(4, dtype=torch.float32, device="cpu" if (staged or device is None) else device)
+    missing = 0
+    try:
+        dist.gather(t, gather_list=[torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0, group=group)
+    except NotImplementedError:
+        missing = 1
+    except RuntimeError as e:
+        if "not supported" not in str(e).lower() and "not implemented" not in str(e).lower():
+            raise
+        missing = 1
+    flag = torch.tensor([missing], dtype=torch.int32, device=t.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return bool(flag.item())
+
+
+def gather_frame(local, nh: int, nw: int, shard_rows: int = DEFAULT_SHARD_ROWS, dst: int = 0, group=None, out=None,
+                 use_all_gather: bool = False):
     """Gather shard accumulators ([padded_rows, nw, 3] f32 tensors, one per rank) to rank `dst` and
-    place their rows into the full frame [nh, nw, 3].  Returns the frame on `dst`, None elsewhere."""
+    place their rows into the full frame [nh, nw, 3].  Returns the frame on `dst`, None elsewhere.
+    `use_all_gather` (from probe_gather, the same on every rank) selects all_gather for backends without gather."""
     import torch
     import torch.distributed as dist
 
@@ -48,18 +76,14 @@ def gather_frame(local, nh: int, nw: int, shard_rows: int = DEFAULT_SHARD_ROWS, 
     staged = local.is_cuda and dist.get_backend(group) != "nccl"
     send = local.cpu() if staged else local
     parts = None
-    try:
-        if rank == dst:
-            parts = [torch.empty_like(send) for _ in range(world)]
-            dist.gather(send, gather_list=parts, dst=dst, group=group)
-        else:
-            dist.gather(send, gather_list=None, dst=dst, group=group)
-    except (NotImplementedError, RuntimeError) as e:
-        # a backend build without gather raises before anything is sent, on every rank alike: all-gather instead
-        if "gather" not in str(e).lower() and not isinstance(e, NotImplementedError):
-            raise
+    if use_all_gather:
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(parts, send, group=group)
+    elif rank == dst:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, gather_list=parts, dst=dst, group=group)
+    else:
+        dist.gather(send, gather_list=None, dst=dst, group=group)
     if rank != dst:
         return None
     frame = out if out is not None else torch.empty((nh, nw, 3), dtype=local.dtype, device=local.device)
@@ -85,13 +109,13 @@ class ShardedSampler:
     """Sampler for rank `rank` of `world` GPUs: execute() renders this rank's rows and gathers the frame
     on rank 0; img() is served by rank 0 (Sampler::img needs every row)."""
 
-    def __init__(self, render, rank: int, world: int, device: int, seed: int = 1, shard_rows: int = DEFAULT_SHARD_ROWS):
+    def __init__(self, render, rank: int, world: int, device: int, seed: int = 1, shard_rows: int = DEFAULT_SHARD_ROWS, flags: int = 0):
         import torch
         from .sampler import Sampler
 
         self.rank, self.world, self.shard_rows = rank, world, shard_rows
         self.render = render
-        self.s = Sampler(seed=seed, device=device, shard_index=rank, shard_count=world, shard_rows=shard_rows).create(render)
+        self.s = Sampler(seed=seed, device=device, shard_index=rank, shard_count=world, shard_rows=shard_rows, flags=flags).create(render)
         self.nw, self.nh = self.s.nw, self.s.nh
         pr = self.s.padded_rows()
         assert pr == padded_rows(self.nh, world, shard_rows)
@@ -101,17 +125,23 @@ class ShardedSampler:
         self.s.bind_accum(self.local.data_ptr(), self.local.numel() * 4)
         self.frame = torch.zeros((self.nh, self.nw, 3), dtype=torch.float32, device=self.dev) if rank == 0 else None
         self.count = 0
+        self.use_all_gather = probe_gather(self.dev) if world > 1 else False
+        self.last_gather_ms = 0.0       # wall time of the last exchange on this rank (gather + row placement, synchronised)
 
     def execute(self, n_samples: int = 1, gather: bool = True):
         secs = self.s.execute(self.render, n_samples=n_samples)
         self.count += n_samples
+        self.last_gather_ms = 0.0
         if gather:
-            gather_frame(self.local, self.nh, self.nw, self.shard_rows, dst=0, out=self.frame)
+            import time
+            t0 = time.perf_counter()
+            gather_frame(self.local, self.nh, self.nw, self.shard_rows, dst=0, out=self.frame, use_all_gather=self.use_all_gather)
             if self.world > 1:
                 # like mrt_execute, return only when the exchange is done: the next launch (on the library's own stream)
                 # accumulates into the buffer the collective is still reading
                 import torch
                 torch.cuda.current_stream(self.dev).synchronize()
+                self.last_gather_ms = (time.perf_counter() - t0) * 1e3
         return secs
 
     def img(self):

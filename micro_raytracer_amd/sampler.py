@@ -19,24 +19,61 @@ from . import _abi, _lib
 from .scene import Render
 
 
+def _fingerprint(render: Render):
+    """What the device context was built from, cheap enough to recompute on every execute (the reference's
+    Sampler::execute receives scene, frame and rt on every call, src/sampler.rs:28): every scalar and small vector by
+    value; bulk arrays (mesh triangles, texels, long instance lists) by identity and shape."""
+    def arr(a):
+        if a is None:
+            return None
+        a = np.asarray(a)
+        return a.tobytes() if a.size <= 64 else (id(a), a.shape)
+
+    def tex(t):
+        return None if t is None else (t.w, t.h, arr(t.dat))
+
+    cam = render.frame.cam
+    out = [render.rt.bounce, render.rt.loss, tuple(render.frame.res), render.frame.ssaa,
+           arr(cam.pos), arr(cam.dir), cam.fov, cam.gamma, cam.exp, cam.aprt, cam.foc,
+           arr(render.scene.sky.color), render.scene.sky.pwr]
+    for l in render.scene.light:
+        out.append((l.kind, arr(l.v), l.pwr, arr(l.color)))
+    for o in render.scene.renderer:
+        m = o.mat
+        inst = tuple((arr(p), arr(d)) for p, d in o.inst) if len(o.inst) <= 16 else (id(o.inst), len(o.inst), arr(o.inst[0][0]), arr(o.inst[-1][0]))
+        out.append((o.kind, o.r, arr(o.n), arr(o.sizes), arr(o.vtx), arr(o.mesh), arr(m.albedo), m.rough, m.metal, m.glass,
+                    m.opacity, m.emit, tuple(tex(getattr(m, k)) for k in _abi.MAP_SLOTS), inst))
+    return tuple(out)
+
+
 class Sampler:
     def __init__(self, workers: int = 24, n_dim: int = 64, *, seed: int = 1, device: int = -1,
-                 shard_index: int = 0, shard_count: int = 1, shard_rows: int = 8, n_devices: int = 0):
+                 shard_index: int = 0, shard_count: int = 1, shard_rows: int = 8, n_devices: int = 0, flags: int = 0):
         self.workers, self.n_dim = workers, n_dim
         self.seed, self.device = seed, device
         self.shard_index, self.shard_count, self.shard_rows = shard_index, shard_count, shard_rows
         self.n_devices = n_devices      # > 1: one process drives that many GPUs (RCCL gather inside mrt_execute)
+        self.flags = flags              # _abi.FLAG_COUNT_SEGMENTS: keep the path-segment counter (stats()["segments"])
         self._ctx = None
         self._holder = None
-        self._key = None
+        self._render = None             # strong reference: the context belongs to THIS description (id() of a dead
+        self._print = None              # temporary is reused by CPython), and to its contents at creation time
         self.nw = self.nh = self.local_rows = 0
         self.res = (0, 0)
 
     # -- context -----------------------------------------------------------------------------
     def _ensure(self, render: Render):
-        key = id(render)
-        if self._ctx is not None and key == self._key:
+        fp = _fingerprint(render)
+        if self._ctx is not None and render is self._render and fp == self._print:
             return
+        # Another description, or this one edited in place: the device context is rebuilt from what is passed NOW.
+        # Like the reference's Sampler, what has been accumulated so far is kept when the supersampled frame keeps
+        # its size (src/sampler.rs:60-70 adds into the same map whatever the scene); a different size starts afresh.
+        carry = None
+        if self._ctx is not None and self.shard_count == 1 and self.n_devices <= 1:
+            old_dims = (self.nw, self.nh)
+            if old_dims == (render.frame.nw, render.frame.nh):
+                carry = self.accum()
         self.close()
         L = _lib.lib()
         self._holder = _abi.build_desc(render)
@@ -46,19 +83,23 @@ class Sampler:
         opts.device = self.device
         opts.shard_index, opts.shard_count, opts.shard_rows = self.shard_index, self.shard_count, self.shard_rows
         opts.n_devices = self.n_devices
+        opts.flags = self.flags
         ctx = L.mrt_create(C.cast(self._holder.ptr(), C.c_void_p), C.byref(opts))
         if not ctx:
             raise _lib.MrtError(L.mrt_last_status(), L.mrt_last_error().decode())
-        self._ctx, self._key = ctx, key
+        self._ctx, self._render, self._print = ctx, render, fp
         nw, nh, lr = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _lib.check(L.mrt_dims(ctx, C.byref(nw), C.byref(nh), C.byref(lr)))
         self.nw, self.nh, self.local_rows = nw.value, nh.value, lr.value
         self.res = tuple(render.frame.res)
+        if carry is not None and carry[1] > 0:
+            self.set_accum(*carry)
 
     def close(self):
         if self._ctx is not None:
             _lib.lib().mrt_destroy(self._ctx)
             self._ctx = None
+        self._render = self._print = None
 
     def __del__(self):
         try:

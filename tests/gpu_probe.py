@@ -11,7 +11,7 @@ from micro_raytracer_amd import Sampler, load_render, scenes
 
 def run(name, desc, spp, reps=3):
     r = load_render(desc)
-    s = Sampler(seed=1)
+    s = Sampler(seed=1, flags=1)
     s.execute(r, n_samples=1)
     best = None
     for _ in range(reps):

@@ -12,7 +12,7 @@ from micro_raytracer_amd.scene import load_render  # noqa: E402
 
 def run(name, desc, spp):
     render = load_render(desc)
-    s = Sampler(seed=1, device=0).create(render)
+    s = Sampler(seed=1, device=0, flags=1).create(render)
     s.execute(render, n_samples=spp)
     t = time.perf_counter()
     s.execute(render, n_samples=spp)

@@ -27,14 +27,16 @@ def _worker(rank, world, port, out_path, no_gather=False):
     import torch
     import torch.distributed as dist
     from micro_raytracer_amd import _abi, load_render, scenes
-    from micro_raytracer_amd.dist import gather_frame, padded_rows, shard_row_index
+    from micro_raytracer_amd.dist import gather_frame, padded_rows, probe_gather, shard_row_index
     from oracle import oracle
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    if no_gather:          # a backend without gather: gather_frame must fall back to all_gather on every rank alike
+    if no_gather:          # a backend without gather: the one-time probe must switch every rank to all_gather
         def _refuse(*a, **k):
             raise NotImplementedError("gather is not implemented by this backend")
         dist.gather = _refuse
+    use_all_gather = probe_gather()                 # once, agreed across ranks (ShardedSampler does this at construction)
+    assert use_all_gather == bool(no_gather)
     render = load_render(scenes.cornell_box2(res=(40, 44), ssaa=1, sample=2))
     h = _abi.build_desc(render)
     o = oracle.Oracle(h, seed=4)
@@ -50,7 +52,7 @@ def _worker(rank, world, port, out_path, no_gather=False):
             full[b0:b0 + 8] = a[b0:b0 + 8]
     local = torch.zeros((padded_rows(nh, world), nw, 3), dtype=torch.float32)
     local[: len(rows)] = torch.from_numpy(full[rows])
-    frame = gather_frame(local, nh, nw, dst=0)
+    frame = gather_frame(local, nh, nw, dst=0, use_all_gather=use_all_gather)
     if rank == 0:
         np.save(out_path, frame.numpy())
     dist.barrier()
@@ -109,3 +111,17 @@ def test_shard_row_index_partitions_every_row():
             assert len(rows) <= padded_rows(nh, world, sr)
             seen[rows] += 1
         assert (seen == 1).all()
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_relays_failure():
+    """`python bench.py --gpus 2` without WORLD_SIZE spawns two fresh ranks through torch.distributed.run before
+    touching a GPU; without a device each rank stops with the no-CPU-path message and the exit code is non-zero."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered on the GPU box by tests/test_gpu_dist.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs a GPU") >= 2, out.stderr[-2000:]

@@ -40,7 +40,7 @@ def test_edge_case_gpu(name, oracle_mod):
     spp = render.rt.sample
     o = oracle_mod.Oracle(h, seed=17)
     o.execute(spp)
-    s = Sampler(seed=17)
+    s = Sampler(seed=17, flags=1)          # MRT_FLAG_COUNT_SEGMENTS
     s.execute(render, n_samples=spp)
     got, cnt = s.accum()
     assert cnt == spp

@@ -14,9 +14,11 @@ pytestmark = pytest.mark.gpu
 
 
 def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """Plain `python bench.py --gpus 2` (no torchrun, no WORLD_SIZE): bench.py starts its ranks itself."""
     env = dict(os.environ, MRT_DIST_BACKEND="gloo", MRT_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--workload", "cornell_512_64spp_b8", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -24,6 +26,20 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["samples_per_step"] == 512 * 512 * 64
+    r = d["roofline"]
+    assert r["gather_ms"] > 0 and 0 < r["kernel_ms_rank_min"] <= r["kernel_ms_rank_max"]
+
+
+def test_bench_under_torchrun_still_works():
+    """The driver's form: python -m torch.distributed.run ... bench.py --gpus 2."""
+    env = dict(os.environ, MRT_DIST_BACKEND="gloo", MRT_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--workload", "cornell_512_64spp_b8", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0
 
 
 def _worker(rank, world, port, out_path):
@@ -78,7 +94,7 @@ plain.execute(render, n_samples=16)
 plain.execute(render, n_samples=4)
 ref, cnt = plain.accum()
 os.environ["MRT_FORCE_RCCL"] = "1"
-g = Sampler(seed=3, n_devices=1)
+g = Sampler(seed=3, n_devices=1, flags=1)
 g.execute(render, n_samples=16)
 st = g.stats()
 assert st["samples"] == 120 * 72 * 16 and st["segments"] > 0

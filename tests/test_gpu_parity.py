@@ -259,3 +259,88 @@ def test_more_shards_than_row_blocks_and_context_churn():
         s = Sampler(seed=1)
         s.execute(render, n_samples=1)
         s.close()
+
+
+def test_one_execute_is_cut_into_bounded_launches_without_changing_a_bit(monkeypatch):
+    """mrt_execute bounds the sample-split buffer by cutting a large n_samples into launches of at most 64 chunks
+    (1024 samples): 4096 samples in one call == 4 x 1024 == k_split 1, bit for bit, and the launch count shows the cut."""
+    from micro_raytracer_amd import Sampler, scenes
+    render, _ = make_holder(scenes.cornell_box(res=(256, 256), sample=4096, bounce=3))
+    a = Sampler(seed=5)
+    a.execute(render, n_samples=4096)
+    sa = a.stats()
+    assert sa["k_split"] > 1 and sa["launches"] == 4, sa
+    ra, ca = a.accum()
+    b = Sampler(seed=5)
+    for _ in range(4):
+        b.execute(render, n_samples=1024)
+        assert b.stats()["launches"] == 1
+    rb, cb = b.accum()
+    assert ca == cb == 4096 and np.array_equal(ra.view(np.uint32), rb.view(np.uint32))
+    a.close(); b.close()
+    # a small cap (tests only) and an unaligned start: launches end on chunk boundaries of the GLOBAL sample index
+    small, _ = make_holder(scenes.cornell_box2(res=(96, 64), ssaa=1, sample=200))
+    monkeypatch.setenv("MRT_K_SPLIT", "1")
+    ref = Sampler(seed=5)
+    ref.execute(small, n_samples=5)
+    ref.execute(small, n_samples=195)
+    assert ref.stats()["launches"] == 1
+    monkeypatch.setenv("MRT_K_SPLIT", "4")
+    monkeypatch.setenv("MRT_MAX_CHUNKS", "4")
+    c = Sampler(seed=5)
+    c.execute(small, n_samples=5)
+    c.execute(small, n_samples=195)          # chunks 0..12, four per launch -> 4 launches
+    assert c.stats()["launches"] == 4 and c.stats()["k_split"] == 4
+    assert np.array_equal(ref.accum()[0].view(np.uint32), c.accum()[0].view(np.uint32))
+
+
+def test_sample_split_falls_back_to_one_lane_per_pixel_when_the_buffer_cannot_be_had(monkeypatch):
+    """No room for the chunk planes (forced here through the test-only byte limit): the launch runs with k_split 1 and
+    the same bits; a failed allocation must not poison the launch that follows (HIP 7 keeps the last real error)."""
+    from micro_raytracer_amd import scenes
+    render, _ = make_holder(scenes.cornell_box2(res=(96, 64), ssaa=1, sample=64))
+    ref = _gpu_render(render, 64)
+    assert ref.stats()["k_split"] > 1
+    monkeypatch.setenv("MRT_PARTIAL_LIMIT_BYTES", "1000")
+    s = _gpu_render(render, 64)
+    assert s.stats()["k_split"] == 1
+    assert np.array_equal(ref.accum()[0].view(np.uint32), s.accum()[0].view(np.uint32))
+    monkeypatch.delenv("MRT_PARTIAL_LIMIT_BYTES")
+    monkeypatch.setenv("MRT_PARTIAL_FAIL_ALLOC", "1")         # the hipMalloc route: an impossible size, tolerated
+    f = _gpu_render(render, 64)
+    assert f.stats()["k_split"] == 1
+    assert np.array_equal(ref.accum()[0].view(np.uint32), f.accum()[0].view(np.uint32))
+    f.execute(render, n_samples=16)                           # and the context keeps working
+    assert f.accum()[1] == 80
+
+
+def test_segment_counter_only_with_the_flag():
+    """MRT_FLAG_COUNT_SEGMENTS (include/mrt.h): without it the per-call path has no counter reduction, no atomic and no
+    blocking read-back, and mrt_stats.segments stays 0; with it the counter counts."""
+    from micro_raytracer_amd import Sampler, _abi, scenes
+    render, _ = make_holder(scenes.cornell_box(res=(64, 48), sample=4))
+    plain = Sampler(seed=5)
+    plain.execute(render, n_samples=4)
+    st = plain.stats()
+    assert st["segments"] == 0 and st["samples"] == 64 * 48 * 4 and st["kernel_ms"] > 0
+    counted = Sampler(seed=5, flags=_abi.FLAG_COUNT_SEGMENTS)
+    counted.execute(render, n_samples=4)
+    sc = counted.stats()
+    assert 64 * 48 * 4 <= sc["segments"] <= 64 * 48 * 4 * 9
+    assert np.array_equal(plain.accum()[0], counted.accum()[0])
+
+
+def test_per_call_loop_equals_one_batched_call():
+    """The reference's callers run one Sampler::execute per sample (src/cli.rs:162-170, src/http.rs:141-144): 32 x
+    mrt_execute(ctx, 1) accumulates the same samples as mrt_execute(ctx, 32); chunk sums are re-associated (<= 1e-6)."""
+    from micro_raytracer_amd import Sampler, scenes
+    render, _ = make_holder(scenes.cornell_box(res=(96, 64), sample=32))
+    a = _gpu_render(render, 32)
+    b = Sampler(seed=5)
+    for _ in range(32):
+        b.execute(render)
+    ra, ca = a.accum()
+    rb, cb = b.accum()
+    assert ca == cb == 32
+    assert np.abs(ra - rb).max() / 32 <= 1e-6
+    assert np.array_equal(a.img(), b.img()) or np.abs(a.img().astype(int) - b.img().astype(int)).max() <= 1
