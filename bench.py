@@ -33,6 +33,9 @@ WORKLOADS = {
     # the same frame driven the way the reference's unmodified callers drive the boundary: one Sampler::execute per sample
     # (src/cli.rs:162-170, src/http.rs:141-144) = 1024 x mrt_execute(ctx, 1) per step
     "cornell_1080p_percall": (dict(kind="cornell_box", res=(1920, 1080), bounce=8), 1024),
+    # the same loop with MRT_FLAG_DEFER (what MRT_DEFER=1 gives the unmodified binary): calls only book their sample,
+    # the frame is traced in 1024-sample batches when it is observed
+    "cornell_1080p_percall_deferred": (dict(kind="cornell_box", res=(1920, 1080), bounce=8), 1024),
     "cornell_512_64spp_b8": (dict(kind="cornell_box", res=(512, 512), bounce=8), 64),           # BASELINE.json configs[1]
     "cornell2_4k_64spp_b16": (dict(kind="cornell_box2", res=(1920, 1080), ssaa=2, bounce=16), 64),  # configs[2] geometry
     # the BASELINE.json configs at their full sizes (one step = the whole render)
@@ -163,7 +166,13 @@ def main():
     if args.spp:
         spp = args.spp
     render = build_render(spec, spp)
-    ss = ShardedSampler(render, rank, world, local_rank, seed=1, flags=1)     # MRT_FLAG_COUNT_SEGMENTS: the VALU model needs segments
+    percall = "_percall" in args.workload
+    deferred = args.workload.endswith("_deferred")
+    # MRT_FLAG_COUNT_SEGMENTS (1): the VALU model needs segments.  Not in the per-call loops: one atomic per wavefront on one
+    # counter word (32 400 short wavefronts per 1080p pass) would be what is measured; their segment count comes from one
+    # batched pass outside the timed region.  MRT_FLAG_DEFER (4) for the deferred loop.
+    flags = (4 if deferred else 0) if percall else 1
+    ss = ShardedSampler(render, rank, world, local_rank, seed=1, flags=flags)
     nw, nh = ss.nw, ss.nh
 
     def sync():
@@ -172,7 +181,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    percall = args.workload.endswith("_percall")
+    seg_per_pass = 0.0
+    if percall:                                  # segments of one sample pass, from a counted context (not timed)
+        probe = ShardedSampler(render, rank, world, local_rank, seed=1, flags=1)
+        probe.execute(16, gather=False)
+        seg_per_pass = probe.s.stats()["segments"] / 16.0
+        probe.close()
 
     def step():
         """One step.  Batched: one mrt_execute(ctx, spp).  Per call: spp x mrt_execute(ctx, 1), each synchronous like
@@ -183,8 +197,8 @@ def main():
             return st["kernel_ms"], st["segments"]
         for i in range(spp):
             ss.execute(1, gather=(i == spp - 1))
-        st = ss.s.stats()                       # stats of the LAST call only: the per-call path reads nothing back per call
-        return st["kernel_ms"] * spp, st["segments"] * spp
+        st = ss.s.stats()                       # stats of the LAST call only (deferred: of the one batch this observation triggers)
+        return st["kernel_ms"] * (1 if deferred else spp), seg_per_pass * spp
 
     for _ in range(args.warmup):
         step()
@@ -222,15 +236,15 @@ def main():
         px_local = ss.s.local_rows * nw
         alg_bytes = 24.0 * px_local + st["scene_bytes"]
         alg_bytes_8d = alg_bytes
-        if percall:
+        if percall and not deferred:
             pass                                 # every pass is a launch: 24 B per pixel + the scene, per launch
         elif st["k_split"] > 1:          # sample split: pt_megakernel writes one f32x3 chunk sum per pixel per 16 samples (reduce_chunks,
             alg_bytes = 12.0 * px_local * ((spp + 15) // 16) + st["scene_bytes"]     # timed apart, folds them into the accumulator)
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        if percall:
+        if percall and not deferred:
             k_ms /= spp                          # per launch (estimated from the last call of each step)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        seg_local = segments / max(1, args.steps) / (spp if percall else 1)
+        seg_local = segments / max(1, args.steps) / (spp if (percall and not deferred) else 1)
         valu_tflops = seg_local * FLOP_PER_SEGMENT / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         line = {
             "metric": "Msamples/sec (res x spp)", "value": samples / elapsed / 1e6, "unit": "Msamples/s",

@@ -154,7 +154,16 @@ typedef struct mrt_opts {
     uint32_t reserved[4];
 } mrt_opts;
 
-#define MRT_FLAG_COUNT_SEGMENTS 1u   /* keep the per-launch path-segment counter (mrt_stats) */
+#define MRT_FLAG_COUNT_SEGMENTS 1u   /* keep the per-launch path-segment counter (mrt_stats.segments): one wave reduction and
+                                        one atomic per wavefront, a read-back when mrt_get_stats is called */
+#define MRT_FLAG_NO_EVENT_TIMING 2u  /* no HIP events around the kernels (mrt_stats.kernel_ms / reduce_ms stay 0): what a caller that
+                                        runs one sample per call (src/cli.rs:162-170) and never asks for stats wants */
+#define MRT_FLAG_DEFER 4u            /* mrt_execute only books its samples; they are traced, batched, when 1024 are booked or when
+                                        the accumulator is observed or replaced (mrt_accum*, mrt_img*, mrt_set_accum*, mrt_get_stats,
+                                        mrt_bind_accum).  Same samples, same image as eager execution (sums re-associated like any
+                                        batched call); the Duration of a booking call is ~0.  Also set by the environment variable
+                                        MRT_DEFER=1 for unmodified callers.  Ignored while the accumulator's device memory is
+                                        visible to the caller (mrt_bind_accum / mrt_accum_device_ptr). */
 
 typedef struct mrt_ctx mrt_ctx;
 
@@ -250,6 +259,13 @@ int mrt_device_count(void);
 /* Test hook: run one device math-contract function elementwise on the GPU.
  * op: 0 sin, 1 cos, 2 acos, 3 atan2(a,b), 4 pow(a,b), 5 1/a, 6 sqrt(a), 7 a/b.  b may be NULL for unary ops. */
 int mrt_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n);
+
+/* Test hook: compare, on the device, the fast correctly rounded cores of the math contract (sqrt, 1/x, a/b and the
+ * 1/sqrt(m) of Vec3f::norm, src/lin.rs:60-66) with the compiler's full IEEE expansions, on `count` inputs generated
+ * from the indices first .. first+count-1: op 0 sqrt and op 1 recip take the index as the f32 bit pattern (first = 0,
+ * count = 2^32 covers every float); op 2 divide and op 3 norm scale hash (seed, index) into operands.
+ * *mismatches = number of differing results (NaN == NaN); example[4] = {a, b, fast, reference} of one of them. */
+int mrt_selftest_sweep(int device, int op, uint64_t first, uint64_t count, uint32_t seed, uint64_t *mismatches, float *example);
 
 #ifdef __cplusplus
 }

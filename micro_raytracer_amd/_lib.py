@@ -14,7 +14,7 @@ SYMBOLS = (
     "mrt_create", "mrt_destroy", "mrt_execute", "mrt_dims", "mrt_accum", "mrt_accum_local", "mrt_accum_device_ptr",
     "mrt_set_accum", "mrt_img", "mrt_img_ss", "mrt_reset", "mrt_get_stats", "mrt_last_error", "mrt_last_status",
     "mrt_abi_version", "mrt_device_count", "mrt_selftest_math", "mrt_padded_rows", "mrt_bind_accum",
-    "mrt_set_accum_device", "mrt_save_image",
+    "mrt_set_accum_device", "mrt_save_image", "mrt_selftest_sweep",
 )
 
 
@@ -69,6 +69,7 @@ def lib():
     L.mrt_set_accum_device.argtypes = [vp, vp, u32]
     L.mrt_save_image.argtypes = [C.c_char_p, u8p, u32, u32]
     L.mrt_selftest_math.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p, C.c_size_t]
+    L.mrt_selftest_sweep.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, u32, C.POINTER(C.c_uint64), f32p]
     _LIB = L
     return L
 
@@ -90,6 +91,15 @@ def selftest_math(op, a, b=None, device=0):
     check(lib().mrt_selftest_math(device, op, a.ctypes.data_as(C.POINTER(C.c_float)), bp,
                                   out.ctypes.data_as(C.POINTER(C.c_float)), a.size))
     return out
+
+
+def selftest_sweep(op, first, count, seed=1, device=0):
+    """(mismatches, example[4]) of mrt_selftest_sweep: fast IEEE cores vs the compiler's expansions, on the device."""
+    import numpy as np
+    mis = C.c_uint64()
+    ex = np.zeros(4, np.float32)
+    check(lib().mrt_selftest_sweep(device, op, first, count, seed, C.byref(mis), ex.ctypes.data_as(C.POINTER(C.c_float))))
+    return mis.value, ex
 
 
 def save_image(path, rgb8):

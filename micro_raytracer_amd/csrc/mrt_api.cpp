@@ -109,6 +109,10 @@ struct mrt_ctx {
     u32 ev_used = 0;
     bool stats_pending = false;                   // event times / segment counter of the last execute not read back yet
     bool count_segments = false;                  // MRT_FLAG_COUNT_SEGMENTS
+    bool event_timing = true;                     // !MRT_FLAG_NO_EVENT_TIMING
+    bool defer = false;                           // MRT_FLAG_DEFER / MRT_DEFER=1
+    bool exposed = false;                         // the accumulator's device memory is visible to the caller (bound or handed out): no deferral
+    u32 pending = 0;                              // samples requested by deferred mrt_execute calls and not traced yet
     Packed pk;
     Params P;
     u32 *d_blob = nullptr;
@@ -283,11 +287,13 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         c->P.persist_grid = c->block_threads > 64u && !getenv("MRT_NO_PERSIST") ? (u32)(n_cu * per_cu) : 0u;
     }
     c->count_segments = (opts->flags & MRT_FLAG_COUNT_SEGMENTS) != 0;
+    c->event_timing = (opts->flags & MRT_FLAG_NO_EVENT_TIMING) == 0;
     c->P.count_segments = c->count_segments ? 1u : 0u;
     memset(&c->stats, 0, sizeof c->stats);
     c->stats.lds_bytes = (u32)pt_lds_bytes(c->pk.P, c->block_threads, c->scene_in_lds, c->pk.features);
     c->stats.block_threads = c->block_threads;
     c->stats.scene_bytes = (u32)blob_bytes;
+    c->defer = (opts->flags & MRT_FLAG_DEFER) != 0 || (getenv("MRT_DEFER") != nullptr && opts->shard_count <= 1);
     ok();
     return c;
 }
@@ -304,12 +310,14 @@ static mrt_ctx *create_group(const mrt_render_desc *desc, const mrt_opts *opts, 
     const int rc = pack_scene(desc, g->pk, err);
     if (rc != MRT_OK) { fail(rc, "mrt_create: %s", err.c_str()); delete g; return nullptr; }
     g->device = 0; g->seed = opts->seed;
+    g->defer = (opts->flags & MRT_FLAG_DEFER) != 0 || getenv("MRT_DEFER") != nullptr;
     g->shard_count = 1; g->shard_index = 0; g->shard_rows = opts->shard_rows ? opts->shard_rows : 8;
     g->local_rows = g->pk.nh; g->padded_rows = g->pk.nh;
     for (u32 y = 0; y < g->pk.nh; ++y) g->row_of.push_back(y);
     for (u32 r = 0; r < n; ++r) {
         mrt_opts o = *opts;
         o.n_devices = 0; o.device = (int)r; o.shard_index = r; o.shard_count = n; o.shard_rows = g->shard_rows;
+        o.flags &= ~MRT_FLAG_DEFER;                   // the group defers, not its shards
         mrt_ctx *sub = create_single(desc, &o);
         if (!sub) { free_ctx(g); return nullptr; }
         g->subs.push_back(sub);
@@ -439,12 +447,11 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
         while (c->evs.size() < (size_t)c->ev_used + 3u) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->evs.push_back(e); }
         hipEvent_t *ev = &c->evs[c->ev_used];
         if (persist) HIP_TRY(hipMemsetAsync(c->P.tile_counter, 0, sizeof(u32), c->stream));
-        HIP_TRY(hipEventRecord(ev[0], c->stream));
+        if (c->event_timing) HIP_TRY(hipEventRecord(ev[0], c->stream));
         HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
-        HIP_TRY(hipEventRecord(ev[1], c->stream));
+        if (c->event_timing) HIP_TRY(hipEventRecord(ev[1], c->stream));
         if (ks > 1u) HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_partial, (size_t)c->local_rows * c->pk.nw * 3, plane, nc, c->stream));
-        HIP_TRY(hipEventRecord(ev[2], c->stream));
-        c->ev_used += 3u;
+        if (c->event_timing) { HIP_TRY(hipEventRecord(ev[2], c->stream)); c->ev_used += 3u; }
         c->stats.launches += 1u;
         base = stop;
     }
@@ -511,18 +518,38 @@ static int exec_group(mrt_ctx *g, uint32_t n_samples)
     return MRT_OK;
 }
 
+static int run_samples(mrt_ctx *c, uint32_t n_samples)
+{
+    int rc;
+    if (!c->subs.empty()) return exec_group(c, n_samples);
+    if ((rc = exec_launch(c, n_samples))) return rc;
+    return exec_finish(c, n_samples);
+}
+
+// Deferred execution (MRT_FLAG_DEFER): trace what earlier mrt_execute calls only booked.  Called by every entry point that
+// observes or replaces the accumulator; the result is the same set of samples as if each call had run at once.
+static int settle(mrt_ctx *c)
+{
+    if (!c->pending) return MRT_OK;
+    const u32 n = c->pending;
+    c->pending = 0;
+    return run_samples(c, n);
+}
+constexpr u32 kDeferLimit = 1024u;        // booked samples that trigger a launch by themselves (one full-size batch)
+
 int mrt_execute(mrt_ctx *c, uint32_t n_samples, double *seconds)
 {
     if (!c) return fail(MRT_ERR_ARG, "mrt_execute: null context");
-    if ((unsigned long long)c->count + n_samples > 0xffffffffull) return fail(MRT_ERR_LIMIT, "mrt_execute: sample count overflows u32");
+    if ((unsigned long long)c->count + c->pending + n_samples > 0xffffffffull) return fail(MRT_ERR_LIMIT, "mrt_execute: sample count overflows u32");
     const auto t0 = std::chrono::steady_clock::now();
-    int rc;
-    if (!c->subs.empty()) {
-        if ((rc = exec_group(c, n_samples))) return rc;
+    int rc = MRT_OK;
+    if (c->defer && !c->exposed) {
+        c->pending += n_samples;
+        if (c->pending >= kDeferLimit) rc = settle(c);
     } else {
-        if ((rc = exec_launch(c, n_samples))) return rc;
-        if ((rc = exec_finish(c, n_samples))) return rc;
+        rc = run_samples(c, n_samples);
     }
+    if (rc) return rc;
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ok();
     return MRT_OK;
@@ -543,6 +570,7 @@ int mrt_accum_local(mrt_ctx *c, float *rgb, uint32_t *rows)
     if (!c) return fail(MRT_ERR_ARG, "mrt_accum_local: null context");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = settle(c))) return rc;
     if (!c->subs.empty()) {       // a multi-device context owns every row
         if (rows) memcpy(rows, c->row_of.data(), sizeof(u32) * c->local_rows);
         if (rgb) HIP_TRY(hipMemcpy(rgb, c->d_full, (size_t)c->pk.nh * c->pk.nw * 3 * sizeof(float), hipMemcpyDeviceToHost));
@@ -560,6 +588,7 @@ int mrt_accum(mrt_ctx *c, float *rgb, uint32_t *count)
     if (!c) return fail(MRT_ERR_ARG, "mrt_accum: null context");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = settle(c))) return rc;
     const size_t row_bytes = (size_t)c->pk.nw * 3 * sizeof(float);
     if (rgb) {
         if (c->d_full) {
@@ -580,6 +609,8 @@ int mrt_accum(mrt_ctx *c, float *rgb, uint32_t *count)
 int mrt_accum_device_ptr(mrt_ctx *c, void **dev_ptr, size_t *bytes)
 {
     if (!c) return fail(MRT_ERR_ARG, "mrt_accum_device_ptr: null context");
+    { int rc = set_device(c); if (rc) return rc; if ((rc = settle(c))) return rc; }
+    c->exposed = true;                        // from now on the caller may read the accumulator behind the library's back
     if (dev_ptr) *dev_ptr = c->subs.empty() ? c->d_accum : c->d_full;
     if (bytes) *bytes = (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float);
     ok();
@@ -600,6 +631,8 @@ int mrt_bind_accum(mrt_ctx *c, void *dev_ptr, size_t bytes)
     if (!c->subs.empty()) return fail(MRT_ERR_STATE, "mrt_bind_accum: not available on a multi-device context");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = settle(c))) return rc;
+    c->exposed = dev_ptr != nullptr;          // the caller reads this memory whenever it likes: every execute runs at once
     const size_t need = (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float);
     float *dst = dev_ptr ? (float *)dev_ptr : c->d_accum_own;
     if (dev_ptr && bytes < need) return fail(MRT_ERR_ARG, "mrt_bind_accum: buffer of %zu bytes, need %zu", bytes, need);
@@ -617,6 +650,7 @@ int mrt_set_accum_device(mrt_ctx *c, const void *dev_rgb, uint32_t count)
     if (!c || !dev_rgb) return fail(MRT_ERR_ARG, "mrt_set_accum_device: null argument");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = settle(c))) return rc;
     const size_t bytes = (size_t)c->pk.nw * c->pk.nh * 3 * sizeof(float);
     if (!c->subs.empty()) return fail(MRT_ERR_STATE, "mrt_set_accum_device: use mrt_set_accum on a multi-device context");
     if (c->shard_count == 1) {
@@ -636,6 +670,7 @@ int mrt_set_accum(mrt_ctx *c, const float *rgb, uint32_t count)
     if (!c || !rgb) return fail(MRT_ERR_ARG, "mrt_set_accum: null argument");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = settle(c))) return rc;
     const size_t row_bytes = (size_t)c->pk.nw * 3 * sizeof(float);
     if (!c->subs.empty()) {
         HIP_TRY(hipMemcpy(c->d_full, rgb, row_bytes * c->pk.nh, hipMemcpyHostToDevice));
@@ -662,6 +697,7 @@ int mrt_set_accum(mrt_ctx *c, const float *rgb, uint32_t count)
 int mrt_reset(mrt_ctx *c)
 {
     if (!c) return fail(MRT_ERR_ARG, "mrt_reset: null context");
+    c->pending = 0;                           // booked samples of a deferred context are dropped with everything else
     int rc = set_device(c);
     if (rc) return rc;
     if (!c->subs.empty()) {
@@ -726,6 +762,7 @@ int mrt_img_ss(mrt_ctx *c, uint8_t *rgb8)
     if (!c || !rgb8) return fail(MRT_ERR_ARG, "mrt_img_ss: null argument");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = settle(c))) return rc;
     if ((rc = img_prepare(c))) return rc;
     if ((rc = img_tonemap(c))) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -741,6 +778,7 @@ int mrt_img(mrt_ctx *c, uint8_t *rgb8)
     if (!c || !rgb8) return fail(MRT_ERR_ARG, "mrt_img: null argument");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = settle(c))) return rc;
     if ((rc = img_prepare(c))) return rc;
     if ((rc = img_tonemap(c))) return rc;
     const u32 nw = c->pk.nw, nh = c->pk.nh, rw = c->pk.res_w, rh = c->pk.res_h;
@@ -765,6 +803,7 @@ int mrt_img(mrt_ctx *c, uint8_t *rgb8)
 int mrt_get_stats(const mrt_ctx *c, mrt_stats *out)
 {
     if (!c || !out) return fail(MRT_ERR_ARG, "mrt_get_stats: null argument");
+    if (c->pending) { int rc = set_device(c); if (rc) return rc; if ((rc = settle(const_cast<mrt_ctx *>(c)))) return rc; }
     if (c->stats_pending) { const int rc = resolve_stats(const_cast<mrt_ctx *>(c)); if (rc) return rc; }
     *out = c->stats;
     ok();
@@ -796,6 +835,43 @@ int mrt_selftest_math(int device, int op, const float *a, const float *b, float 
     if (dout) (void)hipFree(dout);
     if (db) (void)hipFree(db);
     if (rc) return rc;
+    ok();
+    return MRT_OK;
+}
+
+int mrt_selftest_sweep(int device, int op, uint64_t first, uint64_t count, uint32_t seed, uint64_t *mismatches, float *example)
+{
+    if (!mismatches) return fail(MRT_ERR_ARG, "mrt_selftest_sweep: null argument");
+    if (op < 0 || op > 3) return fail(MRT_ERR_ARG, "mrt_selftest_sweep: op %d", op);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MRT_ERR_DEVICE, "mrt_selftest_sweep: no HIP device");
+    if (device < 0) device = 0;
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d_mis = nullptr;
+    float *d_ex = nullptr;
+    unsigned long long mis = 0;
+    float ex[4] = {0, 0, 0, 0};
+    auto run = [&]() -> int {
+        HIP_TRY(hipMalloc((void **)&d_mis, sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&d_ex, 4 * sizeof(float)));
+        HIP_TRY(hipMemset(d_mis, 0, sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d_ex, 0, 4 * sizeof(float)));
+        const uint64_t slice = 1ull << 28;                 // one launch per 2^28 elements
+        for (uint64_t done = 0; done < count; done += slice) {
+            const uint64_t n = count - done < slice ? count - done : slice;
+            HIP_TRY(launch_math_sweep(op, first + done, n, seed, d_mis, d_ex, nullptr));
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&mis, d_mis, sizeof mis, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ex, d_ex, sizeof ex, hipMemcpyDeviceToHost));
+        return MRT_OK;
+    };
+    const int rc = run();
+    if (d_mis) (void)hipFree(d_mis);
+    if (d_ex) (void)hipFree(d_ex);
+    if (rc) return rc;
+    *mismatches = mis;
+    if (example) memcpy(example, ex, sizeof ex);
     ok();
     return MRT_OK;
 }

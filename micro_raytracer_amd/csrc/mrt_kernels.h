@@ -17,5 +17,6 @@ hipError_t launch_lanczos_v(const unsigned char *src, float *dst, u32 sw, u32 dh
 hipError_t launch_lanczos_h(const float *src, unsigned char *dst, u32 sw, u32 dw, u32 dh, const u32 *left, const u32 *count,
                             const float *weight, u32 cap, hipStream_t stream);
 hipError_t launch_math_selftest(int op, const float *a, const float *b, float *out, size_t n, hipStream_t stream);
+hipError_t launch_math_sweep(int op, unsigned long long first, unsigned long long n, u32 seed, unsigned long long *mismatches, float *example, hipStream_t stream);
 
 }  // namespace mrt

@@ -201,9 +201,9 @@ __global__ void math_selftest(int op, const float *a, const float *b, float *out
     case 2: r = acos_(x); break;
     case 3: r = atan2_(x, y); break;
     case 4: r = pow_(x, y); break;
-    case 5: r = 1.0f / x; break;
+    case 5: r = recip_(x); break;
     case 6: r = sqrt_(x); break;
-    case 7: r = x / y; break;
+    case 7: r = div_(x, y); break;
     case 8: r = fmax_(x, y); break;
     case 9: r = fmin_(x, y); break;
     case 10: r = u2f((u32)total_key(x)); break;
@@ -212,6 +212,46 @@ __global__ void math_selftest(int op, const float *a, const float *b, float *out
     default: break;
     }
     out[i] = r;
+}
+
+// Exhaustive / randomised comparison of the wave-uniform fast cores of mrt_math.h (sqrt_, recip_, div_, recip_sqrt_)
+// with the compiler's full IEEE expansions, on the device.  Inputs are generated from the element index:
+//   op 0 sqrt, op 1 recip: x = the bit pattern `first + i` (a sweep of 2^32 indices covers every f32)
+//   op 2 divide, op 3 norm scale (1 / sqrt(x*x + y*y + z*z) as norm() computes it): operands hashed from (seed, first + i);
+//        three wavefronts in four draw exponents inside the fast window (so the cores run), the fourth draws raw
+//        bit patterns (zeros, denormals, infinities, NaNs: the fallback runs).
+// A NaN result matches any NaN (payloads are not part of the contract).  Counts mismatches; keeps one example.
+__device__ inline float sweep_operand(u32 h, bool windowed)
+{
+    if (!windowed) return u2f(h);
+    const u32 e = 127u - 40u + (h >> 9) % 80u;                   // exponent field inside [2^-40, 2^40)
+    return u2f((h & 0x80000000u) | (e << 23) | (mix32(h) & 0x7fffffu));
+}
+__global__ void __launch_bounds__(256) math_sweep(int op, unsigned long long first, unsigned long long n, u32 seed,
+                                                  unsigned long long *mismatches, float *example)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long idx = first + i;
+    const bool windowed = ((idx >> 6) & 3ull) != 3ull;           // per wavefront, so that the wave-uniform fast path is taken
+    const u32 k = mix32((u32)idx ^ seed) + (u32)(idx >> 32) * kGold;
+    float a = 0.0f, b = 0.0f, c = 0.0f, fast = 0.0f, ref = 0.0f;
+    switch (op) {
+    case 0: a = u2f((u32)idx); fast = sqrt_(a); ref = __builtin_sqrtf(a); break;
+    case 1: a = u2f((u32)idx); fast = recip_(a); ref = 1.0f / a; break;
+    case 2: a = sweep_operand(mix32(k + 1u), windowed); b = sweep_operand(mix32(k + 2u), windowed); fast = div_(a, b); ref = a / b; break;
+    case 3: {
+        a = sweep_operand(mix32(k + 1u), windowed); b = sweep_operand(mix32(k + 2u), windowed); c = sweep_operand(mix32(k + 3u), windowed);
+        const float m = a * a + b * b + c * c;
+        fast = recip_sqrt_(m); ref = 1.0f / __builtin_sqrtf(m);
+        break;
+    }
+    default: break;
+    }
+    const bool same = f2u(fast) == f2u(ref) || (fast != fast && ref != ref);
+    if (!same) {
+        if (atomicAdd(mismatches, 1ull) == 0ull) { example[0] = a; example[1] = b; example[2] = fast; example[3] = ref; }
+    }
 }
 
 // ---- launchers (declared in mrt_kernels.h) ----
@@ -332,6 +372,12 @@ hipError_t launch_lanczos_h(const float *src, unsigned char *dst, u32 sw, u32 dw
 hipError_t launch_math_selftest(int op, const float *a, const float *b, float *out, size_t n, hipStream_t stream)
 {
     hipLaunchKernelGGL(math_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_math_sweep(int op, unsigned long long first, unsigned long long n, u32 seed, unsigned long long *mismatches, float *example, hipStream_t stream)
+{
+    hipLaunchKernelGGL(math_sweep, dim3((unsigned)((n + 255ull) / 256ull)), dim3(256), 0, stream, op, first, n, seed, mismatches, example);
     return hipGetLastError();
 }
 

@@ -29,10 +29,105 @@ typedef int32_t i32;
 MRT_HD u32 f2u(float f) { return __builtin_bit_cast(u32, f); }
 MRT_HD float u2f(u32 u) { return __builtin_bit_cast(float, u); }
 MRT_HD float fabs_(float x) { return __builtin_fabsf(x); }
-MRT_HD float sqrt_(float x) { return __builtin_sqrtf(x); }     // IEEE correctly rounded
 MRT_HD float floor_(float x) { return __builtin_floorf(x); }
 MRT_HD float trunc_(float x) { return __builtin_truncf(x); }
-MRT_HD float recip_(float x) { return 1.0f / x; }              // f32::recip
+
+// ---- correctly rounded sqrt, 1/x and a/b without the compiler's range scaffolding -------------------------------
+// The reference's f32 sqrt / recip / division are IEEE correctly rounded, and so is everything here.  hipcc expands
+// them (-fhip-fp32-correctly-rounded-divide-sqrt, denormals on) into a core sequence wrapped in scaling and fix-up
+// code for denormal, huge, zero, infinite and NaN operands: 16 VALU + 4 s_nop for sqrt, v_div_scale x2 / v_div_fmas /
+// v_div_fixup around the division core -- 30 and 25 issue slots (measured, profiles/microbench).  On operands inside
+// the exponent window [2^-40, 2^40] that scaffolding is the identity (v_div_scale returns its operand unscaled with
+// VCC = 0 -- ISA: exponent difference < 96, denominator / reciprocal / quotient normal, numerator exponent > 23 --,
+// v_div_fmas is then a plain fma, v_div_fixup passes a normal quotient through; sqrt scales only below 2^-96), so the
+// core sequences alone give THE SAME BITS there: 10 and 9 slots.  A wavefront takes the core when every active lane
+// is inside the window and the compiler's full expansion otherwise -- one wave-uniform branch, no divergence.
+// mrt_selftest_sweep compares the two on all 2^32 inputs (sqrt, recip) and on 10^10 operand pairs (divide).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MRT_GENERIC_IEEE)
+#define MRT_FAST_IEEE 1
+MRT_HD bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
+#else
+MRT_HD bool wave_all(bool ok) { return ok; }
+#endif
+constexpr float kWinLo = 0x1p-40f, kWinHi = 0x1p+40f;
+MRT_HD bool in_window(float x) { const float a = fabs_(x); return a >= kWinLo && a <= kWinHi; }       // false for NaN, 0, inf
+MRT_HD bool in_window_pos(float x) { return x >= kWinLo && x <= kWinHi; }                               // false for x <= 0 too
+
+#if defined(MRT_FAST_IEEE)
+// v_sqrt_f32 is within 1 ulp; the correctly rounded root is s or a neighbour, picked by the sign of the exact
+// residuals x - s_down * s and x - s_up * s (fma): the compiler's own selection, minus scaling and class checks.
+MRT_HD float sqrt_core_(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = u2f(f2u(s) - 1u), su = u2f(f2u(s) + 1u);
+    const float vd = __builtin_fmaf(-sd, s, x), vu = __builtin_fmaf(-su, s, x);
+    float r = (0.0f >= vd) ? sd : s;
+    r = (0.0f < vu) ? su : r;
+    return r;
+}
+// Newton step on v_rcp_f32, then two residual corrections of the quotient: the compiler's division core
+// (fma(-d, r, 1); r += e r; q = n r; q += fma(-d, q, n) r; q = fma(fma(-d, q, n), r, q)).
+MRT_HD float rcp_refined_(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+MRT_HD float div_core_(float n, float d, float r)      // r = rcp_refined_(d)
+{
+    const float q0 = n * r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r, q1);
+}
+#endif
+
+MRT_HD float sqrt_(float x)                                     // IEEE correctly rounded
+{
+#if defined(MRT_FAST_IEEE)
+    if (wave_all(in_window_pos(x))) return sqrt_core_(x);
+#endif
+    return __builtin_sqrtf(x);
+}
+MRT_HD float recip_(float x)                                    // f32::recip = 1.0 / x, correctly rounded
+{
+#if defined(MRT_FAST_IEEE)
+    if (wave_all(in_window(x))) return div_core_(1.0f, x, rcp_refined_(x));
+#endif
+    return 1.0f / x;
+}
+MRT_HD float div_(float a, float b)                             // a / b, correctly rounded
+{
+#if defined(MRT_FAST_IEEE)
+    if (wave_all(in_window(a) && in_window(b))) return div_core_(a, b, rcp_refined_(b));
+#endif
+    return a / b;
+}
+// two quotients over one denominator (the two roots of Sphere::intersect, src/rt.rs:350-351): one reciprocal
+MRT_HD void div2_(float a0, float a1, float b, float &q0, float &q1)
+{
+#if defined(MRT_FAST_IEEE)
+    if (wave_all(in_window(a0) && in_window(a1) && in_window(b))) {
+        const float r = rcp_refined_(b);
+        q0 = div_core_(a0, b, r);
+        q1 = div_core_(a1, b, r);
+        return;
+    }
+#endif
+    q0 = a0 / b;
+    q1 = a1 / b;
+}
+// 1 / sqrt(m) as the reference computes it (mag().recip(), src/lin.rs:60-66): two correctly rounded operations.
+// m inside the window puts sqrt(m) inside it as well: one test covers both cores.
+MRT_HD float recip_sqrt_(float m)
+{
+#if defined(MRT_FAST_IEEE)
+    if (wave_all(in_window_pos(m))) {
+        const float s = sqrt_core_(m);
+        return div_core_(1.0f, s, rcp_refined_(s));
+    }
+#endif
+    return 1.0f / __builtin_sqrtf(m);
+}
 // Approximate reciprocal (1 ulp, one instruction) for values that only steer conservative culling, never a result.
 MRT_HD float rcp_fast(float x)
 {
@@ -128,8 +223,8 @@ MRT_HD float acos_(float x)
 MRT_HD float atan_pos_(float t)    // t >= 0
 {
     float y0, x;
-    if (t > 2.414213562373095f) { y0 = kPiO2; x = -(1.0f / t); }
-    else if (t > 0.4142135623730950f) { y0 = kPiO4; x = (t - 1.0f) / (t + 1.0f); }
+    if (t > 2.414213562373095f) { y0 = kPiO2; x = -recip_(t); }
+    else if (t > 0.4142135623730950f) { y0 = kPiO4; x = div_(t - 1.0f, t + 1.0f); }
     else { y0 = 0.0f; x = t; }
     const float z = x * x;
     const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
@@ -147,7 +242,7 @@ MRT_HD float atan2_(float y, float x)
     } else if (ay == kInf && ax == kInf) {
         a = kPiO4;
     } else {
-        a = atan_pos_(ay / ax);
+        a = atan_pos_(div_(ay, ax));
     }
     if (x < 0.0f) a = kPi - a;
     return (y < 0.0f) ? -a : a;

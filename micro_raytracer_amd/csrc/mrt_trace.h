@@ -36,6 +36,9 @@ enum : u32 {
 #ifndef MRT_COUNT
 #define MRT_COUNT(counter)
 #endif
+#ifndef MRT_PROBE_INST                 // flat instance index about to be tested (tests/emu/probe2.cpp)
+#define MRT_PROBE_INST(i)
+#endif
 #ifndef MRT_PROBE_TBVH_PART            // (node, first node of the root's right subtree): which half of a triangle BVH is being walked
 #define MRT_PROBE_TBVH_PART(node, right0)
 #endif
@@ -55,7 +58,7 @@ MRT_HD V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }                            
 MRT_HD V3 hadam(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }               // lin.rs:107-113
 MRT_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); } // lin.rs:52-58
 MRT_HD float mag(V3 a) { return sqrt_(a.x * a.x + a.y * a.y + a.z * a.z); }               // lin.rs:60-62
-MRT_HD V3 norm(V3 a) { return muls(a, recip_(mag(a))); }                                  // lin.rs:64-66
+MRT_HD V3 norm(V3 a) { return muls(a, recip_sqrt_(a.x * a.x + a.y * a.y + a.z * a.z)); }   // lin.rs:64-66: self * mag().recip()
 MRT_HD V3 reflect(V3 d, V3 n) { return sub(d, muls(n, 2.0f * dot(d, n))); }               // lin.rs:68-70
 MRT_HD V3 m3mul(const float *m, V3 v)                                                     // lin.rs:344-365
 {
@@ -90,7 +93,14 @@ MRT_HD V3 xf_vec(const float *X, bool ident, V3 v)
 
 MRT_HD V3 recip_patched(V3 d)   // Box::intersect's 1/dir with inf -> 1/E, src/rt.rs:303-316
 {
-    V3 m = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 m;
+#if defined(MRT_FAST_IEEE)
+    if (wave_all(in_window(d.x) && in_window(d.y) && in_window(d.z))) {      // one test for the three reciprocals (mrt_math.h)
+        m = v3(div_core_(1.0f, d.x, rcp_refined_(d.x)), div_core_(1.0f, d.y, rcp_refined_(d.y)), div_core_(1.0f, d.z, rcp_refined_(d.z)));
+        return m;                                                            // finite: nothing to patch
+    }
+#endif
+    m = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (fabs_(m.x) == kInf) m.x = kBig;
     if (fabs_(m.y) == kInf) m.y = kBig;
     if (fabs_(m.z) == kInf) m.z = kBig;
@@ -123,10 +133,11 @@ MRT_HD bool sphere_isect(float r2, V3 oo, V3 rd, float a, float &t0, float &t1)
     if (b > 1e-20f && a > 0.0f && a < 1e18f && disc >= 0.0f) return false;
     MRT_PROBE(PH_SPHERE_MATH);
     const float sq = sqrt_(disc);
-    const float q0 = (-b - sq) / (2.0f * a);
+    float q0, q1;
+    div2_(-b - sq, -b + sq, 2.0f * a, q0, q1);
     if (q0 < 0.0f) return false;
     t0 = q0;
-    t1 = (-b + sq) / (2.0f * a);
+    t1 = q1;
     return true;
 }
 
@@ -152,7 +163,7 @@ MRT_HD bool tri_isect(V3 vp, V3 e0, V3 e1, V3 ro, V3 rd, float &t)
 // Plane::intersect, src/rt.rs:400-412; nn = norm(n), d = (-nn).pos
 MRT_HD bool plane_isect(V3 nn, float d, V3 ro, V3 rd, float &t)
 {
-    const float tt = -(dot(ro, nn) + d) / dot(rd, nn);
+    const float tt = div_(-(dot(ro, nn) + d), dot(rd, nn));
     if (tt <= 0.0f) return false;
     t = tt;
     return true;
@@ -183,12 +194,12 @@ MRT_HD UV box_uv(V3 inv2, V3 hit, V3 pos)
     const V3 p = hadam(sub(hit, pos), inv2);
     const float plo = 1.0f - kE, phi = 1.0f + kE, nlo = -1.0f - kE, nhi = -1.0f + kE;
     UV r;
-    if (in_range(plo, phi, p.x)) { r.x = (0.5f + 0.5f * p.y) / 4.0f + 2.0f / 4.0f; r.y = (0.5f - 0.5f * p.z) / 3.0f + 1.0f / 3.0f; }
-    else if (in_range(nlo, nhi, p.x)) { r.x = (0.5f - 0.5f * p.y) / 4.0f; r.y = (0.5f - 0.5f * p.z) / 3.0f + 1.0f / 3.0f; }
-    else if (in_range(plo, phi, p.y)) { r.x = (0.5f - 0.5f * p.x) / 4.0f + 3.0f / 4.0f; r.y = (0.5f - 0.5f * p.z) / 3.0f + 1.0f / 3.0f; }
-    else if (in_range(nlo, nhi, p.y)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = (0.5f - 0.5f * p.z) / 3.0f + 1.0f / 3.0f; }
-    else if (in_range(plo, phi, p.z)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = (0.5f - 0.5f * p.y) / 3.0f; }
-    else if (in_range(nlo, nhi, p.z)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = (0.5f + 0.5f * p.y) / 3.0f + 2.0f / 3.0f; }
+    if (in_range(plo, phi, p.x)) { r.x = (0.5f + 0.5f * p.y) / 4.0f + 2.0f / 4.0f; r.y = div_(0.5f - 0.5f * p.z, 3.0f) + 1.0f / 3.0f; }
+    else if (in_range(nlo, nhi, p.x)) { r.x = (0.5f - 0.5f * p.y) / 4.0f; r.y = div_(0.5f - 0.5f * p.z, 3.0f) + 1.0f / 3.0f; }
+    else if (in_range(plo, phi, p.y)) { r.x = (0.5f - 0.5f * p.x) / 4.0f + 3.0f / 4.0f; r.y = div_(0.5f - 0.5f * p.z, 3.0f) + 1.0f / 3.0f; }
+    else if (in_range(nlo, nhi, p.y)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = div_(0.5f - 0.5f * p.z, 3.0f) + 1.0f / 3.0f; }
+    else if (in_range(plo, phi, p.z)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = div_(0.5f - 0.5f * p.y, 3.0f); }
+    else if (in_range(nlo, nhi, p.z)) { r.x = (0.5f + 0.5f * p.x) / 4.0f + 1.0f / 4.0f; r.y = div_(0.5f + 0.5f * p.y, 3.0f) + 2.0f / 3.0f; }
     else { r.x = 0.0f; r.y = 0.0f; }
     return r;
 }
@@ -502,6 +513,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     auto consider = [&](u32 i, const F4 &ia, const F4 &ib) -> bool {
         float t0, t1;
         MRT_COUNT(CT_LIN_TEST);
+        MRT_PROBE_INST(i);
         i32 i0, i1;
         if (!isect_instance<ANY, FEAT>(S, ray, i, ia, ib, t0, t1, i0, i1)) return false;
         if (ANY) return true;
@@ -624,7 +636,7 @@ MRT_HD UV hit_uv(const Obj &o, V3 n_hit)
     UV r;
     if (o.kind == KIND_SPHERE) {
         const V3 v = norm(sub(n_hit, o.pos));
-        r.x = 0.5f + 0.5f * atan2_(v.x, -v.y) / kPi;
+        r.x = 0.5f + div_(0.5f * atan2_(v.x, -v.y), kPi);
         r.y = 0.5f - 0.5f * v.z;
     } else if (o.kind == KIND_PLANE) {
         r.x = fract_(n_hit.x + 0.5f);
@@ -701,8 +713,8 @@ MRT_HD bool refract(V3 d, float eta, V3 n, V3 &out)
 // RayTracer::iter + the pixel-only half of RayTracer::cast, src/rt.rs:937-947, 900-914
 MRT_HD V3 pixel_focus(const Params &P, float cx, float cy)
 {
-    const float uvx = P.aspect * (cx - 0.5f * P.w) / P.w;
-    const float uvy = (cy - 0.5f * P.h) / P.h;
+    const float uvx = div_(P.aspect * (cx - 0.5f * P.w), P.w);
+    const float uvy = div_(cy - 0.5f * P.h, P.h);
     const V3 dir = norm(v3(uvx, P.inv2tan, -uvy));
     const V3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     const V3 orig = add(cam, muls(dir, kE));           // Ray::cast_default

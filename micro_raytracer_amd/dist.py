@@ -120,10 +120,13 @@ class ShardedSampler:
         pr = self.s.padded_rows()
         assert pr == padded_rows(self.nh, world, shard_rows)
         self.dev = torch.device("cuda", device)
-        # the accumulator lives in a torch tensor so that RCCL can send it without a copy
-        self.local = torch.zeros((pr, self.nw, 3), dtype=torch.float32, device=self.dev)
-        self.s.bind_accum(self.local.data_ptr(), self.local.numel() * 4)
-        self.frame = torch.zeros((self.nh, self.nw, 3), dtype=torch.float32, device=self.dev) if rank == 0 else None
+        if world > 1:
+            # the accumulator lives in a torch tensor so that RCCL can send it without a copy
+            self.local = torch.zeros((pr, self.nw, 3), dtype=torch.float32, device=self.dev)
+            self.s.bind_accum(self.local.data_ptr(), self.local.numel() * 4)
+            self.frame = torch.zeros((self.nh, self.nw, 3), dtype=torch.float32, device=self.dev) if rank == 0 else None
+        else:
+            self.local = self.frame = None       # one rank: the frame stays inside the library (mrt_accum / mrt_img serve it)
         self.count = 0
         self.use_all_gather = probe_gather(self.dev) if world > 1 else False
         self.last_gather_ms = 0.0       # wall time of the last exchange on this rank (gather + row placement, synchronised)
@@ -132,7 +135,7 @@ class ShardedSampler:
         secs = self.s.execute(self.render, n_samples=n_samples)
         self.count += n_samples
         self.last_gather_ms = 0.0
-        if gather:
+        if gather and self.world > 1:
             import time
             t0 = time.perf_counter()
             gather_frame(self.local, self.nh, self.nw, self.shard_rows, dst=0, out=self.frame, use_all_gather=self.use_all_gather)

@@ -344,3 +344,51 @@ def test_per_call_loop_equals_one_batched_call():
     assert ca == cb == 32
     assert np.abs(ra - rb).max() / 32 <= 1e-6
     assert np.array_equal(a.img(), b.img()) or np.abs(a.img().astype(int) - b.img().astype(int)).max() <= 1
+
+
+def test_deferred_execution_books_calls_and_traces_them_batched():
+    """MRT_FLAG_DEFER: the per-call loop of the reference's callers (src/cli.rs:162-170) only books samples; observing the
+    accumulator traces them in one batch -- bit-identical to one batched call; with an observation after every call
+    (--update, src/cli.rs:166-169) it equals the eager per-call loop; stats, reset and resume behave like eager."""
+    from micro_raytracer_amd import Sampler, _abi, scenes
+    render, _ = make_holder(scenes.cornell_box(res=(96, 64), sample=40))
+    batched = _gpu_render(render, 40)
+    want, _ = batched.accum()
+    d = Sampler(seed=5, flags=_abi.FLAG_DEFER)
+    for _ in range(40):
+        secs = d.execute(render)
+        assert secs < 0.05
+    got, cnt = d.accum()                               # the observation: one launch of 40 samples
+    assert cnt == 40 and np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    assert d.stats()["samples"] == 96 * 64 * 40 and d.stats()["launches"] == 1
+    assert np.array_equal(d.img(), batched.img())
+    # --update: an image after every sample
+    eager, upd = Sampler(seed=5), Sampler(seed=5, flags=_abi.FLAG_DEFER)
+    for _ in range(6):
+        eager.execute(render)
+        upd.execute(render)
+        assert np.array_equal(eager.img(), upd.img())
+    assert np.array_equal(eager.accum()[0].view(np.uint32), upd.accum()[0].view(np.uint32))
+    # more booked samples than one batch: 1024 are traced as soon as they are booked, the rest at the observation
+    small, _ = make_holder(scenes.default_scene(res=(32, 24), sample=1100))
+    big = Sampler(seed=5, flags=_abi.FLAG_DEFER)
+    for _ in range(1100):
+        big.execute(small)
+    ref = Sampler(seed=5)
+    ref.execute(small, n_samples=1024)
+    ref.execute(small, n_samples=76)
+    assert np.array_equal(ref.accum()[0].view(np.uint32), big.accum()[0].view(np.uint32)) and big.accum()[1] == 1100
+    # reset drops what is booked; set_accum settles first
+    big.execute(small)
+    big.reset()
+    assert big.accum()[1] == 0 and not big.accum()[0].any()
+
+
+def test_no_event_timing_flag_leaves_kernel_ms_zero():
+    from micro_raytracer_amd import Sampler, _abi, scenes
+    render, _ = make_holder(scenes.cornell_box(res=(64, 48), sample=4))
+    s = Sampler(seed=5, flags=_abi.FLAG_NO_EVENT_TIMING)
+    s.execute(render, n_samples=4)
+    st = s.stats()
+    assert st["kernel_ms"] == 0 and st["samples"] == 64 * 48 * 4 and st["launches"] == 1
+    assert np.array_equal(s.accum()[0], _gpu_render(render, 4).accum()[0])
