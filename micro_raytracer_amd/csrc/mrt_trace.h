@@ -496,6 +496,8 @@ MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia,
     return false;
 }
 
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
 // RayTracer::closest_hit, src/rt.rs:867-898: every renderer x instance in order, first minimum of the entry distance
 // under f32::total_cmp, i.e. the lexicographic minimum of (total_cmp key, flat instance index) -- which is how the
 // BVH variant, visiting candidates in tree order, returns the very same hit.  ANY = true answers only Some / None
@@ -510,7 +512,10 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     const float *I = F + P.off_inst;
 
     if (ANY) { MRT_COUNT(CT_TRACE_ANY); } else { MRT_COUNT(CT_TRACE); }
-    auto consider = [&](u32 i, const F4 &ia, const F4 &ib) -> bool {
+    // IN_ORDER: candidates arrive in increasing flat index (the linear scan of a scene without an instance BVH), so the
+    // first minimum is kept by a strict comparison alone -- an equal key never replaces an earlier candidate, and the
+    // initial key 0x7fffffff loses to every real one (a NaN distance maps to 0x80000000, the smallest key).
+    auto consider = [&](u32 i, const F4 &ia, const F4 &ib, auto in_order) -> bool {
         float t0, t1;
         MRT_COUNT(CT_LIN_TEST);
         MRT_PROBE_INST(i);
@@ -518,12 +523,16 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         if (!isect_instance<ANY, FEAT>(S, ray, i, ia, ib, t0, t1, i0, i1)) return false;
         if (ANY) return true;
         const i32 key = total_key(t0);
-        if (best.rend < 0 || key < best_key || (key == best_key && i < best.inst)) {
+        const bool better = decltype(in_order)::value ? key < best_key
+                                                      : (best.rend < 0 || key < best_key || (key == best_key && i < best.inst));
+        if (better) {
             best_key = key;
             best.rend = 0; best.inst = i; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
         }
         return false;
     };
+    using InOrder = BoolTag<(FEAT & F_BVH) == 0>;       // BVH scenes keep the general rule for their short linear list too
+    using AnyOrder = BoolTag<false>;
 
     // ---- linear scan: every instance, or (BVH scenes) the ones that cannot be bounded: planes, odd transforms ----
     const bool bvh = (FEAT & F_BVH) != 0;
@@ -539,7 +548,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
                 cur = bvh ? ldu(Lst, j + 1) : j + 1;
                 qa = ld4(I, cur * INST_WORDS); qb = ld4(I, cur * INST_WORDS + 4);
             }
-            if (consider(i, ia, ib)) return true;
+            if (consider(i, ia, ib, InOrder())) return true;
         }
     }
 
@@ -581,7 +590,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
             const u32 cnt_a = leaf_a >> 24, first_a = leaf_a & 0xffffffu, cnt_b = leaf_b >> 24, first_b = leaf_b & 0xffffffu;
             for (u32 k = 0; k < cnt_a + cnt_b; ++k) {
                 const u32 i = ldu(F, P.off_bvhinst + (k < cnt_a ? first_a + k : first_b + (k - cnt_a)));
-                if (consider(i, ld4(I, i * INST_WORDS), ld4(I, i * INST_WORDS + 4))) return true;
+                if (consider(i, ld4(I, i * INST_WORDS), ld4(I, i * INST_WORDS + 4), AnyOrder())) return true;
             }
         }
     }
