@@ -137,6 +137,9 @@ MRT_HD float rcp_fast(float x)
     return 1.0f / x;
 #endif
 }
+// Fused multiply-add, one rounding (fmaf): part of the math contract (version 2) in the transcendentals below -- argument
+// reduction and polynomial steps -- never in the reference's own arithmetic (lin.rs / rt.rs operations stay mul + add).
+MRT_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // a * b + c in one instruction where the hardware has it; like rcp_fast, only for culling arithmetic
 MRT_HD float fma_fast(float a, float b, float c)
 {
@@ -178,18 +181,18 @@ MRT_HD float fmin_(float a, float b)
 #endif
 
 // sin, cos for |x| <= 65536 (NaN beyond): quadrant reduction with a 3-term split of pi/2
-// (8 + 11 + 24 significant bits), then degree-7 / degree-8 polynomials on [-pi/4, pi/4].
+// (8 + 11 + 24 significant bits), then degree-7 / degree-8 polynomials on [-pi/4, pi/4], Horner steps fused.
 MRT_HD void sincos_(float x, float &s, float &c)
 {
     if (!(fabs_(x) <= 65536.0f)) { s = qnan(); c = qnan(); return; }
-    const float kf = floor_(x * 0.636619746685028076f + 0.5f);
-    float r = x - kf * 1.5703125f;
-    r = r - kf * 4.83751296997070312e-4f;
-    r = r - kf * 7.54978995489188216e-8f;
+    const float kf = floor_(fma_(x, 0.636619746685028076f, 0.5f));
+    float r = fma_(-kf, 1.5703125f, x);
+    r = fma_(-kf, 4.83751296997070312e-4f, r);
+    r = fma_(-kf, 7.54978995489188216e-8f, r);
     const float z = r * r;
-    const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    const float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
-                     - 0.5f * z + 1.0f;
+    const float sp = fma_(fma_(fma_(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = fma_(fma_(fma_(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                          fma_(-0.5f, z, 1.0f));
     const int q = (int)kf & 3;
     float ss = (q & 1) ? cp : sp;
     float cc = (q & 1) ? sp : cp;
@@ -202,8 +205,8 @@ MRT_HD void sincos_(float x, float &s, float &c)
 MRT_HD float asin_core_(float a)   // |a| <= 0.5
 {
     const float z = a * a;
-    return ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
-            + 1.6666752422e-1f) * z * a + a;
+    const float p = fma_(fma_(fma_(fma_(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z, 1.6666752422e-1f);
+    return fma_(p * z, a, a);
 }
 
 MRT_HD float acos_(float x)
@@ -227,8 +230,8 @@ MRT_HD float atan_pos_(float t)    // t >= 0
     else if (t > 0.4142135623730950f) { y0 = kPiO4; x = div_(t - 1.0f, t + 1.0f); }
     else { y0 = 0.0f; x = t; }
     const float z = x * x;
-    const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
-    return y0 + p;
+    const float p = fma_(fma_(fma_(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+    return y0 + fma_(p * z, x, x);
 }
 
 MRT_HD float atan2_(float y, float x)

@@ -3,14 +3,17 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may build or load anything in oracle/.
  *
  * The "math contract": every transcendental the path needs, written as a fixed sequence of
- * IEEE-754 binary32 / binary64 operations (+ - * / sqrt floor, round-to-nearest-even, no
- * contraction, denormals kept).  The reference calls Rust's f32::{sin,cos,acos,atan2,powf}
+ * IEEE-754 binary32 / binary64 operations (+ - * / sqrt floor and, where written OM_FMA, the fused
+ * multiply-add; round-to-nearest-even, no implicit contraction, denormals kept).  The reference calls Rust's f32::{sin,cos,acos,atan2,powf}
  * (libm) at src/rt.rs:522,997-1003 and src/sampler.rs:88; libm is not available on the GPU,
  * so the contract pins one concrete f32 result per input that both this oracle and the HIP
  * kernel (micro_raytracer_amd/csrc/mrt_math.h, written independently against DESIGN.md §4)
  * must reproduce bit for bit.  Accuracy is ~1-2 ulp vs libm (tests/test_oracle_math.py).
  *
- * Compile with -ffp-contract=off and without -ffast-math.
+ * Compile with -ffp-contract=off and without -ffast-math.  OM_FMA is fmaf: one rounding, a hardware
+ * instruction on every x86-64 since 2013 (-mfma) and on the GPU; the polynomial and argument-reduction steps of
+ * the transcendentals use it (contract version 2: half the instructions of the mul + add form on the device,
+ * and a slightly smaller error).  The reference's own arithmetic (src/lin.rs, src/rt.rs) is never fused.
  */
 #ifndef ORACLE_MATH_H
 #define ORACLE_MATH_H
@@ -28,6 +31,7 @@ static inline double om_u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f;
 #define OM_PIO2      1.57079637050628662f
 #define OM_PIO4      0.785398185253143311f
 #define OM_QNAN      om_u2f(0x7fc00000u)
+#define OM_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
 /* quadrant reduction constants: pi/2 = P1 + P2 + P3 (+ 2^-60), P1 has 8 significant bits */
 #define OM_TWO_OVER_PI 0.636619746685028076f
@@ -39,14 +43,14 @@ static inline double om_u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f;
 static inline void om_sincosf(float x, float *s, float *c)
 {
     if (!(fabsf(x) <= 65536.0f)) { *s = OM_QNAN; *c = OM_QNAN; return; }
-    float kf = floorf(x * OM_TWO_OVER_PI + 0.5f);
-    float r = x - kf * OM_P1;
-    r = r - kf * OM_P2;
-    r = r - kf * OM_P3;
+    float kf = floorf(OM_FMA(x, OM_TWO_OVER_PI, 0.5f));
+    float r = OM_FMA(-kf, OM_P1, x);
+    r = OM_FMA(-kf, OM_P2, r);
+    r = OM_FMA(-kf, OM_P3, r);
     float z = r * r;
-    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
-               - 0.5f * z + 1.0f;
+    float sp = OM_FMA(OM_FMA(OM_FMA(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    float cp = OM_FMA(OM_FMA(OM_FMA(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                      OM_FMA(-0.5f, z, 1.0f));
     int q = (int)kf & 3;
     float ss = (q & 1) ? cp : sp;
     float cc = (q & 1) ? sp : cp;
@@ -63,9 +67,9 @@ static inline float om_cosf(float x) { float s, c; om_sincosf(x, &s, &c); return
 static inline float om_asin_core(float a)
 {
     float z = a * a;
-    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z
-                + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * a + a;
-    return p;
+    float p = OM_FMA(OM_FMA(OM_FMA(OM_FMA(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z,
+                     1.6666752422e-1f);
+    return OM_FMA(p * z, a, a);
 }
 
 /* acos for x in [-1, 1]; NaN outside (through sqrt of a negative) */
@@ -98,9 +102,8 @@ static inline float om_atan_pos(float t)
         x = t;
     }
     float z = x * x;
-    float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z
-               - 3.33329491539e-1f) * z * x + x;
-    return y0 + p;
+    float p = OM_FMA(OM_FMA(OM_FMA(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+    return y0 + OM_FMA(p * z, x, x);
 }
 
 /* atan2(y, x): result in [-pi, pi]; (0,0) -> 0 (sign of zero ignored: +/-0 are the same input) */
