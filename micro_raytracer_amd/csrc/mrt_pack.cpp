@@ -523,8 +523,8 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
             const H3 pos = h3(in.pos[0], in.pos[1], in.pos[2]);
             ir[INST_POS] = bits(pos.x); ir[INST_POS + 1] = bits(pos.y); ir[INST_POS + 2] = bits(pos.z);
             const u32 xf = xf_of(in.dir);
-            if (xf >= (1u << 28)) { err = "too many distinct instance directions"; return MRT_ERR_LIMIT; }
-            ir[INST_TAG] = o.kind | (bits(xf_tab[(size_t)xf * XF_WORDS + XF_IDENT]) ? TAG_IDENT : 0u) | (xf << TAG_XF_SHIFT);
+            if ((unsigned long long)xf * XF_WORDS >= (1ull << 28)) { err = "too many distinct instance directions"; return MRT_ERR_LIMIT; }
+            ir[INST_TAG] = o.kind | (bits(xf_tab[(size_t)xf * XF_WORDS + XF_IDENT]) ? TAG_IDENT : 0u) | ((xf * XF_WORDS) << TAG_XF_SHIFT);      // word offset of the transform
             ix[INSTX_REND] = r;
             if (o.kind == MRT_KIND_SPHERE) {
                 ir[INST_P3] = rec[REND_GEO];                                                    // r * r

@@ -38,7 +38,7 @@ enum : u32 { RF_HAS_MAPS = 1u };
 // two aligned 16-byte reads, everything the common kinds need):
 //   [0..2] pos
 //   [3]    sphere r*r | plane d = (-n^).pos | box half.x
-//   [4]    tag = kind | identity-valued transform ? 8 : 0 | xf index << 4
+//   [4]    tag = kind | identity-valued transform ? 8 : 0 | (word offset of the transform inside the XF table) << 4
 //   [5..7] plane n^ | box [5] half.y [6] half.z
 // INSTX (read per lane after a hit): [0] renderer index  [1..3] plane world normal norm(R*(L*n))
 enum : u32 { INST_POS = 0, INST_P3 = 3, INST_TAG = 4, INST_P5 = 5 };

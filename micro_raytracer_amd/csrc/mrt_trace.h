@@ -469,7 +469,7 @@ MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia,
     const u32 tag = f2u(ib.x);
     const u32 kind = tag & TAG_KIND_MASK;
     const bool ident = (tag & TAG_IDENT) != 0;
-    const float *X = F + P.off_xf + (tag >> TAG_XF_SHIFT) * XF_WORDS;
+    const float *X = F + P.off_xf + (tag >> TAG_XF_SHIFT);          // the tag carries the word offset of the transform
     // n_ray.orig = pos + R*(L*(orig - pos)), n_ray.dir = R*(L*dir), src/rt.rs:729-733
     const V3 ro = add(pos, xf_vec(X, ident, sub(ray.o, pos)));
     const bool fast_d = ident && ray.d_ok;
@@ -613,7 +613,7 @@ MRT_HD Obj obj_of(const Scn &S, const Hit &h)
     const u32 tag = ldu(I, INST_TAG);
     o.R = S.F + S.P->off_rend + (u32)h.rend * REND_WORDS;
     o.IX = S.F + S.P->off_instx + h.inst * INSTX_WORDS;
-    o.X = S.F + S.P->off_xf + (tag >> TAG_XF_SHIFT) * XF_WORDS;
+    o.X = S.F + S.P->off_xf + (tag >> TAG_XF_SHIFT);
     o.pos = ld3(I, INST_POS);
     o.ident = (tag & TAG_IDENT) != 0;
     o.kind = tag & TAG_KIND_MASK;
