@@ -537,7 +537,21 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     // ---- linear scan: every instance, or (BVH scenes) the ones that cannot be bounded: planes, odd transforms ----
     const bool bvh = (FEAT & F_BVH) != 0;
     const u32 n = bvh ? P.n_lin : P.n_inst;
-    if (n) {
+    if (!bvh && !(FEAT & F_TRI) && n) {          // (with triangle / mesh code the test is too large to have twice)
+        // two record buffers used in turn, each loaded one instance ahead of its use: the next record is in flight
+        // while the current one is tested, and no register copies are needed to keep it (one buffer + a copy per
+        // instance cost 8 v_mov each)
+        u32 j = 0;
+        F4 a0 = ld4(I, 0), a1 = ld4(I, 4), b0 = a0, b1 = a1;
+        for (;;) {
+            if (j + 1u < n) { b0 = ld4(I, (j + 1u) * INST_WORDS); b1 = ld4(I, (j + 1u) * INST_WORDS + 4); }
+            if (consider(j, a0, a1, InOrder())) return true;
+            if (++j >= n) break;
+            if (j + 1u < n) { a0 = ld4(I, (j + 1u) * INST_WORDS); a1 = ld4(I, (j + 1u) * INST_WORDS + 4); }
+            if (consider(j, b0, b1, InOrder())) return true;
+            if (++j >= n) break;
+        }
+    } else if (n) {
         const float *Lst = F + P.off_lin;
         u32 cur = bvh ? ldu(Lst, 0) : 0u;
         F4 qa = ld4(I, cur * INST_WORDS), qb = ld4(I, cur * INST_WORDS + 4);
