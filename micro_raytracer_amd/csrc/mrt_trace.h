@@ -371,9 +371,10 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                 const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
                 const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
                 const bool hit = !(tn > tf || tf < 0.0f);
-                const bool take = hit && leaf != 0u;
-                leaf_b = (take && leaf_a != 0u) ? leaf : leaf_b;
-                leaf_a = (take && leaf_a == 0u) ? leaf : leaf_a;
+                const u32 cand = hit ? leaf : 0u;                  // a leaf to test, or 0
+                const bool have_a = leaf_a != 0u;
+                leaf_b |= have_a ? cand : 0u;
+                leaf_a |= have_a ? 0u : cand;
                 node = (hit && leaf == 0u) ? node + 1u : skip;
                 walking = node != BVH_END && leaf_b == 0u;
             }
@@ -582,6 +583,9 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         for (;;) {
             u32 leaf_a = 0u, leaf_b = 0u;          // one postponed leaf, as in the triangle BVH
             bool walking = node != BVH_END;        // branch-free step: the loop's only branch is its exit
+            // nothing in a node whose near side lies beyond the current closest hit can win; the bound only changes in
+            // the exact tests between two box walks
+            const float far = (!ANY && best.rend >= 0 && best.t0 >= 0.0f) ? best.t0 + 1e-3f * best.t0 : kInf;
             while (walking) {
                 const F4 na = ld4(N0, node * BVH_WORDS), nb = ld4(N0, node * BVH_WORDS + 4);
                 MRT_COUNT(CT_BVH_NODE);
@@ -591,12 +595,12 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
                 const float mg = cull_margin(kMarginInst, r, hh, obig + obig);
                 float tn;
                 bool hit_node = cull_slab(R, r, hh, mg, tn);
-                // nothing in a node whose near side lies beyond the current closest hit can win
-                if (!ANY) hit_node = hit_node && !(best.rend >= 0 && best.t0 >= 0.0f && tn > best.t0 + 1e-3f * best.t0 + mg);
+                if (!ANY) hit_node = hit_node && !(tn > far + mg);
                 hit_node = hit_node || !cull;      // rays that must not be culled visit everything
-                const bool take = hit_node && leaf != 0u;
-                leaf_b = (take && leaf_a != 0u) ? leaf : leaf_b;
-                leaf_a = (take && leaf_a == 0u) ? leaf : leaf_a;
+                const u32 cand = hit_node ? leaf : 0u;             // a leaf to test, or 0
+                const bool have_a = leaf_a != 0u;
+                leaf_b |= have_a ? cand : 0u;
+                leaf_a |= have_a ? 0u : cand;
                 node = (hit_node && leaf == 0u) ? node + 1u : skip;
                 walking = node != BVH_END && leaf_b == 0u;
             }
