@@ -524,8 +524,12 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         if (!isect_instance<ANY, FEAT>(S, ray, i, ia, ib, t0, t1, i0, i1)) return false;
         if (ANY) return true;
         const i32 key = total_key(t0);
-        const bool better = decltype(in_order)::value ? key < best_key
-                                                      : (best.rend < 0 || key < best_key || (key == best_key && i < best.inst));
+        // any order (BVH scenes): the lexicographic minimum of (key, flat index) as ONE unsigned 64-bit compare -- the key with
+        // its sign bit flipped in the high word, the index in the low word; "no candidate yet" is the all-ones pair
+        // (best_key = 0x7fffffff, best.inst = 0xffffffff), below which every real candidate lies
+        const unsigned long long pair = ((unsigned long long)((u32)key ^ 0x80000000u) << 32) | i;
+        const unsigned long long best_pair = ((unsigned long long)((u32)best_key ^ 0x80000000u) << 32) | (best.rend < 0 ? 0xffffffffu : best.inst);
+        const bool better = decltype(in_order)::value ? key < best_key : pair < best_pair;
         if (better) {
             best_key = key;
             best.rend = 0; best.inst = i; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
