@@ -444,8 +444,8 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
         c->P.n_samples = stop - base;
         c->P.sample_base = base;
         c->P.k_split = ks;
-        while (c->evs.size() < (size_t)c->ev_used + 3u) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->evs.push_back(e); }
-        hipEvent_t *ev = &c->evs[c->ev_used];
+        while (c->event_timing && c->evs.size() < (size_t)c->ev_used + 3u) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->evs.push_back(e); }
+        hipEvent_t *ev = c->event_timing ? &c->evs[c->ev_used] : nullptr;
         if (persist) HIP_TRY(hipMemsetAsync(c->P.tile_counter, 0, sizeof(u32), c->stream));
         if (c->event_timing) HIP_TRY(hipEventRecord(ev[0], c->stream));
         HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
