@@ -616,6 +616,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     }
     P.n_lin = (u32)lin_list.size(); P.n_bvh_nodes = (u32)(bvh_nodes.size() / BVH_WORDS);
     out.n_lin = P.n_lin; out.n_bvh_nodes = P.n_bvh_nodes;
+    P.off_cam = B.align4(); for (int k = 0; k < 9; ++k) B.f(P.cam_L[k]); for (int k = 0; k < 9; ++k) B.f(P.cam_R[k]);      // read by the kernel from here (cold path)
     P.off_lin = B.align4(); B.w.insert(B.w.end(), lin_list.begin(), lin_list.end());
     P.off_bvh = B.align4(); for (float v : bvh_nodes) B.f(v);
     P.off_bvhinst = B.align4(); B.w.insert(B.w.end(), bvh_inst.begin(), bvh_inst.end());

@@ -114,6 +114,8 @@ struct Params {
     u32 n_rend, n_light, n_inst;
     u32 n_lin, n_bvh_nodes;   // instance BVH: linear-list length, node count (0: every instance is scanned linearly)
     u32 off_lin, off_bvh, off_bvhinst;
+    u32 off_cam;              // cam_L, cam_R as 18 words of the blob: the kernel reads the matrices from there (only rolled / turned cameras
+                              // need them: kept out of the scalar registers)
     u32 off_rend, off_inst, off_instx, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
     u32 off_tbvh, off_memb, off_membe, off_parent;
     u32 blob_words;

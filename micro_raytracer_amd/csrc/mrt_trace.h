@@ -761,7 +761,7 @@ MRT_HD V3 lens_pos(const Params &P, u32 pk)
     return v3(P.cam_pos[0] + (u1 - 0.5f) * P.aprt, P.cam_pos[1], P.cam_pos[2] + (u2 - 0.5f) * P.aprt);
 }
 
-MRT_HD void camera_ray(const Params &P, V3 focus, u32 pk, V3 &o, V3 &d)
+MRT_HD void camera_ray(const Params &P, const float *camF, V3 focus, u32 pk, V3 &o, V3 &d)      // camF: cam_L, cam_R in the blob
 {
     const float u1 = u32_to_unit(draw_u32(pk, DIM_LENS_X));
     const float u2 = u32_to_unit(draw_u32(pk, DIM_LENS_Z));
@@ -769,7 +769,7 @@ MRT_HD void camera_ray(const Params &P, V3 focus, u32 pk, V3 &o, V3 &d)
     const V3 new_dir = norm(sub(focus, pos));
     // rot_y * (look * new_dir): both matrices are the identity as values for the default camera direction
     if (P.cam_ident && nzfin3(new_dir)) d = new_dir;
-    else d = m3mul(P.cam_R, m3mul(P.cam_L, new_dir));
+    else d = m3mul(camF + 9, m3mul(camF, new_dir));
     o = add(pos, muls(d, kE));
 }
 
@@ -859,7 +859,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     u32 seg = 0;
     if (alive) {                                 // first sample of this lane: every lane of the wavefront is here
         pk = mix32(pix_key + s * kGold);
-        camera_ray(P, st_get3(st, ST_FOCUS), pk, o, d);
+        camera_ray(P, S.F + P.off_cam, st_get3(st, ST_FOCUS), pk, o, d);
     }
 
     // ONE flat loop: an iteration traces one segment; a lane whose path ends draws its next sample's lens position in
@@ -1007,7 +1007,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
         }
         // next ray: dir = X.norm(), orig = base + dir * E  (Ray::cast src/rt.rs:551-553; cast_default :555-557)
         V3 nd = norm(X);
-        if (from_camera && !(P.cam_ident && nzfin3(nd))) nd = m3mul(P.cam_R, m3mul(P.cam_L, nd));   // rot_y * (look * new_dir), src/rt.rs:930
+        if (from_camera && !(P.cam_ident && nzfin3(nd))) nd = m3mul(S.F + P.off_cam + 9, m3mul(S.F + P.off_cam, nd));   // rot_y * (look * new_dir), src/rt.rs:930
         o = add(base, muls(nd, kE));
         d = nd;
     }
