@@ -40,7 +40,7 @@ constexpr int waves_for(u32 feat)
 #ifdef MRT_WAVES_PER_EU
     return MRT_WAVES_PER_EU;
 #else
-    return (feat & (F_LIGHTS | F_TRI | F_BVH)) == 0 ? 6 : 4;      // the BVH walks need their registers more than two extra waves
+    return (feat & ~F_BOX) == 0 ? 7 : ((feat & (F_LIGHTS | F_TRI | F_BVH)) == 0 ? 6 : 4);      // the BVH walks need their registers more than two extra waves
 #endif
 }
 
