@@ -110,6 +110,12 @@ g.set_accum(ref, cnt)                     # resume: push a frame back into the s
 g.execute(render, n_samples=12)
 plain.execute(render, n_samples=12)
 assert np.array_equal(g.accum()[0], plain.accum()[0])
+d = Sampler(seed=3, n_devices=1, flags=4)        # MRT_FLAG_DEFER on the group: 20 per-sample calls, one gathered batch at the observation
+for _ in range(20):
+    d.execute(render)
+got, dcnt = d.accum()
+assert dcnt == 20 and np.array_equal(got, ref)
+assert d.stats()["launches"] == 1
 print("GROUP-OK")
 """
 
