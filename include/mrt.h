@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 2u
+#define MRT_ABI_VERSION 3u
 
 /* ---- error codes (reference: Result<_, String> everywhere, src/sampler.rs:80, src/cli.rs:155) ---- */
 #define MRT_OK            0
@@ -162,7 +162,7 @@ typedef struct mrt_opts {
                                         the accumulator is observed or replaced (mrt_accum*, mrt_img*, mrt_set_accum*, mrt_get_stats,
                                         mrt_bind_accum).  Same samples, same image as eager execution (sums re-associated like any
                                         batched call); the Duration of a booking call is ~0.  Also set by the environment variable
-                                        MRT_DEFER=1 for unmodified callers.  Ignored while the accumulator's device memory is
+                                        MRT_DEFER=1 (a non-zero number; "0" or empty is off) for unmodified callers.  Ignored while the accumulator's device memory is
                                         visible to the caller (mrt_bind_accum / mrt_accum_device_ptr). */
 
 typedef struct mrt_ctx mrt_ctx;
@@ -179,9 +179,13 @@ typedef struct mrt_stats {
     uint32_t block_threads;  /* workgroup size                                                   */
     uint32_t scene_bytes;    /* packed scene bytes staged per workgroup                          */
     uint32_t k_split;        /* lanes per pixel of the last execute (sample chunks dealt round-robin) */
-    uint32_t reserved;
+    uint32_t deferred;       /* 1 when the last mrt_execute was booked under MRT_FLAG_DEFER / MRT_DEFER=1, 0 when it ran at once
+                                (no deferral asked for, or the accumulator's device memory is visible to the caller) */
     double   img_ms;         /* HIP-event time of the kernels of the last mrt_img / mrt_img_ss (tone map + resize) */
     double   reduce_ms;      /* HIP-event time of reduce_chunks after the path-tracing kernel (0 when k_split == 1) */
+    uint32_t kernel_features; /* which instantiation of the path-tracing kernel serves this context: its FEAT template argument
+                                 (csrc/mrt_trace.h F_* bits), i.e. pt_megakernel<scene_in_lds, block_threads, kernel_features> */
+    uint32_t scene_in_lds;   /* 1: every workgroup stages the packed scene in LDS; 0: it is read through L2 */
 } mrt_stats;
 
 /* Sampler::new + the first half of Sampler::execute's argument list (src/sampler.rs:19,28):
@@ -245,7 +249,9 @@ int mrt_save_image(const char *path, const uint8_t *rgb8, uint32_t w, uint32_t h
 /* Zero the accumulators and last_count (a fresh Sampler on the same scene). */
 int mrt_reset(mrt_ctx *ctx);
 
-int mrt_get_stats(const mrt_ctx *ctx, mrt_stats *out);
+/* Counters of the last execute.  Not const: under deferred execution this is an observation (booked samples are traced
+ * first), and the HIP-event times / the segment counter are read back here, lazily. */
+int mrt_get_stats(mrt_ctx *ctx, mrt_stats *out);
 
 /* Result<_, String>'s message for the calling thread's last failed call ("" if none). */
 const char *mrt_last_error(void);

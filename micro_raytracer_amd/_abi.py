@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 KIND_SPHERE, KIND_PLANE, KIND_BOX, KIND_TRIANGLE, KIND_MESH = range(5)
 LIGHT_POINT, LIGHT_DIR = 0, 1
@@ -76,8 +76,8 @@ class Opts(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("samples", C.c_uint64),
                 ("segments", C.c_uint64), ("launches", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("block_threads", C.c_uint32), ("scene_bytes", C.c_uint32), ("k_split", C.c_uint32), ("reserved", C.c_uint32), ("img_ms", C.c_double),
-                ("reduce_ms", C.c_double)]
+                ("block_threads", C.c_uint32), ("scene_bytes", C.c_uint32), ("k_split", C.c_uint32), ("deferred", C.c_uint32), ("img_ms", C.c_double),
+                ("reduce_ms", C.c_double), ("kernel_features", C.c_uint32), ("scene_in_lds", C.c_uint32)]
 
 
 MAP_SLOTS = ("tex", "rmap", "mmap", "gmap", "omap", "emap")

@@ -99,19 +99,46 @@ constexpr unsigned long long kSplitTargetWaves = 120000ull;
 constexpr u32 kMaxChunksPerLaunch = 64u;
 constexpr size_t kPartialBudgetBytes = (size_t)4u << 30;
 
+// an environment switch is on when it holds a non-zero number ("MRT_DEFER=0" and an empty value are off)
+bool env_on(const char *name)
+{
+    const char *v = getenv(name);
+    return v && *v && strtol(v, nullptr, 10) != 0;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for every instantiation: once per device, not per mrt_create
+constexpr int kMaxDevices = 64;
+std::once_flag g_cfg_once[kMaxDevices];
+hipError_t g_cfg_result[kMaxDevices];
+hipError_t configure_pt_once(int device)      // the caller has made `device` current
+{
+    if (device < 0 || device >= kMaxDevices) return configure_pt(kLdsLimit);
+    std::call_once(g_cfg_once[device], [device]() { g_cfg_result[device] = configure_pt(kLdsLimit); });
+    return g_cfg_result[device];
+}
+
 }  // namespace
 
 struct mrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // img timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // img timing; on a group context: around scatter_rows
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;  // sub-context of a group: around this rank's part of the ncclGather, on its stream
     std::vector<hipEvent_t> evs;                  // 3 per launch of the last execute: start, after pt_megakernel, after reduce_chunks
     u32 ev_used = 0;
     bool stats_pending = false;                   // event times / segment counter of the last execute not read back yet
     bool count_segments = false;                  // MRT_FLAG_COUNT_SEGMENTS
     bool event_timing = true;                     // !MRT_FLAG_NO_EVENT_TIMING
     bool defer = false;                           // MRT_FLAG_DEFER / MRT_DEFER=1
-    bool exposed = false;                         // the accumulator's device memory is visible to the caller (bound or handed out): no deferral
+    bool handed_out = false;                      // mrt_accum_device_ptr gave the raw device pointer away: sticky, the caller may read it at any time
+    bool bound = false;                           // the accumulator lives in caller memory (a successful mrt_bind_accum)
+    bool exposed() const { return handed_out || bound; }   // either way the memory is visible behind the library's back: no deferral
+    // test / experiment knobs, read from the environment ONCE in mrt_create (a thread-per-connection server calls
+    // mrt_execute per sample: no getenv on that path)
+    u32 knob_k_split = 0;                         // MRT_K_SPLIT: forced lanes per pixel (0: policy)
+    u32 knob_max_chunks = 0;                      // MRT_MAX_CHUNKS: chunks per launch (0: kMaxChunksPerLaunch)
+    size_t knob_partial_budget = 0;               // MRT_PARTIAL_LIMIT_BYTES (0: kPartialBudgetBytes)
+    bool knob_partial_fail = false;               // MRT_PARTIAL_FAIL_ALLOC: the chunk-plane allocation asks for an impossible size
     u32 pending = 0;                              // samples requested by deferred mrt_execute calls and not traced yet
     Packed pk;
     Params P;
@@ -165,6 +192,8 @@ void free_ctx(mrt_ctx *c)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
+    if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -268,7 +297,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     c->block_threads = want;
     c->pk.P.tiles_x = want == 64u ? 1u : (want == 256u ? 2u : 4u);
     c->pk.P.tiles_y = want == 64u ? 1u : (want == 1024u ? 4u : 2u);
-    if (c->scene_in_lds && (e = configure_pt(kLdsLimit)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipFuncSetAttribute", e);
+    if (c->scene_in_lds && (e = configure_pt_once(dev)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipFuncSetAttribute", e);
 
     c->P = c->pk.P;
     c->P.local_rows = c->local_rows; c->P.shard_index = c->shard_index; c->P.shard_count = c->shard_count; c->P.shard_rows = c->shard_rows;
@@ -293,7 +322,13 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     c->stats.lds_bytes = (u32)pt_lds_bytes(c->pk.P, c->block_threads, c->scene_in_lds, c->pk.features);
     c->stats.block_threads = c->block_threads;
     c->stats.scene_bytes = (u32)blob_bytes;
-    c->defer = (opts->flags & MRT_FLAG_DEFER) != 0 || (getenv("MRT_DEFER") != nullptr && opts->shard_count <= 1);
+    c->stats.kernel_features = pt_instantiation(c->block_threads, c->scene_in_lds, c->pk.features);
+    c->stats.scene_in_lds = c->scene_in_lds ? 1u : 0u;
+    c->defer = (opts->flags & MRT_FLAG_DEFER) != 0 || (env_on("MRT_DEFER") && opts->shard_count <= 1);
+    if (const char *f = getenv("MRT_K_SPLIT")) { const int v = atoi(f); c->knob_k_split = v < 1 ? 1u : (u32)v; }                        // experiments / tests
+    if (const char *f = getenv("MRT_MAX_CHUNKS")) { const int v = atoi(f); if (v > 0) c->knob_max_chunks = (u32)v; }                   // tests
+    if (const char *f = getenv("MRT_PARTIAL_LIMIT_BYTES")) c->knob_partial_budget = (size_t)strtoull(f, nullptr, 10);                  // tests
+    c->knob_partial_fail = getenv("MRT_PARTIAL_FAIL_ALLOC") != nullptr;                                                                // tests
     ok();
     return c;
 }
@@ -310,7 +345,7 @@ static mrt_ctx *create_group(const mrt_render_desc *desc, const mrt_opts *opts, 
     const int rc = pack_scene(desc, g->pk, err);
     if (rc != MRT_OK) { fail(rc, "mrt_create: %s", err.c_str()); delete g; return nullptr; }
     g->device = 0; g->seed = opts->seed;
-    g->defer = (opts->flags & MRT_FLAG_DEFER) != 0 || getenv("MRT_DEFER") != nullptr;
+    g->defer = (opts->flags & MRT_FLAG_DEFER) != 0 || env_on("MRT_DEFER");
     g->shard_count = 1; g->shard_index = 0; g->shard_rows = opts->shard_rows ? opts->shard_rows : 8;
     g->local_rows = g->pk.nh; g->padded_rows = g->pk.nh;
     for (u32 y = 0; y < g->pk.nh; ++y) g->row_of.push_back(y);
@@ -344,6 +379,7 @@ static mrt_ctx *create_group(const mrt_render_desc *desc, const mrt_opts *opts, 
     g->P = g->pk.P;
     memset(&g->stats, 0, sizeof g->stats);
     g->stats.block_threads = g->subs[0]->block_threads; g->stats.lds_bytes = g->subs[0]->stats.lds_bytes; g->stats.scene_bytes = g->subs[0]->stats.scene_bytes;
+    g->stats.kernel_features = g->subs[0]->stats.kernel_features; g->stats.scene_in_lds = g->subs[0]->stats.scene_in_lds;
     ok();
     return g;
 }
@@ -408,12 +444,12 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
     const unsigned long long wave_tiles = (unsigned long long)((c->pk.nw + 7) / 8) * ((c->local_rows + 7) / 8);
     u32 k_split = 1;
     while (k_split * 2u <= n_chunks && k_split < 16u && wave_tiles * k_split < kSplitTargetWaves) k_split *= 2u;
-    if (const char *f = getenv("MRT_K_SPLIT")) { k_split = (u32)atoi(f); if (k_split < 1u) k_split = 1u; while (k_split > n_chunks) k_split /= 2u; }
+    if (c->knob_k_split) { k_split = c->knob_k_split; while (k_split > n_chunks) k_split /= 2u; }
     const size_t plane = (size_t)c->padded_rows * c->pk.nw * 3;
     u32 cap = kMaxChunksPerLaunch;                       // chunks per launch
-    if (const char *f = getenv("MRT_MAX_CHUNKS")) { const int v = atoi(f); if (v > 0) cap = (u32)v; }        // tests
+    if (c->knob_max_chunks) cap = c->knob_max_chunks;
     size_t budget = kPartialBudgetBytes;
-    if (const char *f = getenv("MRT_PARTIAL_LIMIT_BYTES")) budget = (size_t)strtoull(f, nullptr, 10);         // tests
+    if (c->knob_partial_budget) budget = c->knob_partial_budget;
     if (k_split > 1u) {
         if (cap < k_split) cap = k_split;
         while (cap > k_split && plane * cap * sizeof(float) > budget) cap /= 2u;
@@ -421,7 +457,7 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
         if (need * sizeof(float) > budget) k_split = 1u;                       // not even k_split planes fit: one lane per pixel
         else if (need > c->partial_floats) {
             if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_floats = 0; }
-            const size_t ask = getenv("MRT_PARTIAL_FAIL_ALLOC") ? ((size_t)1 << 60) : need * sizeof(float);      // tests: an impossible size
+            const size_t ask = c->knob_partial_fail ? ((size_t)1 << 60) : need * sizeof(float);
             if (!hip_tolerated(hipMalloc((void **)&c->d_partial, ask))) { c->d_partial = nullptr; k_split = 1u; }
             else c->partial_floats = need;
         }
@@ -481,12 +517,22 @@ static int exec_group(mrt_ctx *g, uint32_t n_samples)
     // the caller may free; the first error is the one reported
     auto drain = [&](u32 upto) { for (u32 r = 0; r < upto; ++r) { if (hipSetDevice(g->subs[r]->device) == hipSuccess) (void)hipStreamSynchronize(g->subs[r]->stream); } (void)hipGetLastError(); };
     if (rc) { const std::string keep = g_err; drain(launched + (launched < n ? 1u : 0u)); g_err = keep; g_status = rc; return rc; }
-    // one gather per batch: rank r sends its padded shard accumulator, device 0 receives rank i at offset i * plane
-    const auto tg = std::chrono::steady_clock::now();
+    // one gather per batch: rank r sends its padded shard accumulator, device 0 receives rank i at offset i * plane.
+    // gather_ms is device time, not host time around asynchronous launches: every sub-stream records an event after its
+    // kernels (before its part of the gather) and one after it; the slowest stream's interval plus scatter_rows is the
+    // exchange.  A rank whose kernels finish early waits inside the collective for the slowest one, so the figure is an
+    // upper bound of the transfer itself; kernel_ms (the slowest rank's kernels) is reported next to it.
     const size_t plane = (size_t)g->subs[0]->padded_rows * g->pk.nw * 3;
-    int nrc = g_rccl.GroupStart();
     hipError_t he = hipSuccess;
-    if (nrc == 0) {
+    for (u32 r = 0; r < n && he == hipSuccess; ++r) {
+        mrt_ctx *s = g->subs[r];
+        if ((he = hipSetDevice(s->device)) != hipSuccess) break;
+        if (!s->ev_g0 && (he = hipEventCreate(&s->ev_g0)) != hipSuccess) break;
+        if (!s->ev_g1 && (he = hipEventCreate(&s->ev_g1)) != hipSuccess) break;
+        he = hipEventRecord(s->ev_g0, s->stream);
+    }
+    int nrc = he == hipSuccess ? g_rccl.GroupStart() : 0;
+    if (he == hipSuccess && nrc == 0) {
         for (u32 r = 0; r < n && nrc == 0 && he == hipSuccess; ++r) {
             if ((he = hipSetDevice(g->subs[r]->device)) != hipSuccess) break;
             nrc = g_rccl.Gather(g->subs[r]->d_accum, r == 0 ? g->d_gather : nullptr, plane, kNcclFloat, 0, g->comms[r], g->subs[r]->stream);
@@ -494,27 +540,40 @@ static int exec_group(mrt_ctx *g, uint32_t n_samples)
         const int nrc2 = g_rccl.GroupEnd();                         // always closed, whatever happened inside the group
         if (nrc == 0) nrc = nrc2;
     }
+    for (u32 r = 0; r < n && he == hipSuccess && nrc == 0; ++r) {
+        if ((he = hipSetDevice(g->subs[r]->device)) != hipSuccess) break;
+        he = hipEventRecord(g->subs[r]->ev_g1, g->subs[r]->stream);
+    }
     if (he != hipSuccess || nrc != 0) {
         drain(n);
-        if (he != hipSuccess) return fail(MRT_ERR_DEVICE, "hipSetDevice failed inside the gather group: %s", hipGetErrorString(he));
+        if (he != hipSuccess) return fail(MRT_ERR_DEVICE, "HIP call failed around the gather group: %s", hipGetErrorString(he));
         return fail(MRT_ERR_DEVICE, "ncclGather: %s", g_rccl.GetErrorString(nrc));
     }
     for (mrt_ctx *s : g->subs) if ((rc = exec_finish(s, n_samples))) { const std::string keep = g_err; drain(n); g_err = keep; g_status = rc; return rc; }    // syncs every stream (kernel + gather)
     HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipEventRecord(g->ev0, g->stream));
     HIP_TRY(launch_scatter_rows(g->d_full, g->d_gather, g->d_rowmap, n * g->subs[0]->padded_rows, g->pk.nw * 3u, g->stream));
+    HIP_TRY(hipEventRecord(g->ev1, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     g->count += n_samples;
     g->full_count = g->count;
     memset(&g->stats, 0, offsetof(mrt_stats, lds_bytes));
     g->stats.reduce_ms = 0;
+    double gather_ms = 0;
     for (mrt_ctx *s : g->subs) {
         if ((rc = resolve_stats(s))) return rc;
         if (s->stats.kernel_ms > g->stats.kernel_ms) g->stats.kernel_ms = s->stats.kernel_ms;
         if (s->stats.reduce_ms > g->stats.reduce_ms) g->stats.reduce_ms = s->stats.reduce_ms;
         g->stats.samples += s->stats.samples; g->stats.segments += s->stats.segments; g->stats.launches += s->stats.launches;
+        float ms = 0;
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_g0, s->ev_g1));
+        if (ms > gather_ms) gather_ms = ms;
     }
+    HIP_TRY(hipSetDevice(g->device));
+    { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, g->ev0, g->ev1)); gather_ms += ms; }      // + placing the rows into the frame
     g->stats.k_split = g->subs[0]->stats.k_split;
-    g->stats.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg).count();
+    g->stats.gather_ms = gather_ms;
     return MRT_OK;
 }
 
@@ -543,13 +602,15 @@ int mrt_execute(mrt_ctx *c, uint32_t n_samples, double *seconds)
     if ((unsigned long long)c->count + c->pending + n_samples > 0xffffffffull) return fail(MRT_ERR_LIMIT, "mrt_execute: sample count overflows u32");
     const auto t0 = std::chrono::steady_clock::now();
     int rc = MRT_OK;
-    if (c->defer && !c->exposed) {
+    const bool deferred = c->defer && !c->exposed();
+    if (deferred) {
         c->pending += n_samples;
         if (c->pending >= kDeferLimit) rc = settle(c);
     } else {
         rc = run_samples(c, n_samples);
     }
     if (rc) return rc;
+    c->stats.deferred = deferred ? 1u : 0u;       // whether THIS call was booked (MRT_FLAG_DEFER honoured) or ran at once
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ok();
     return MRT_OK;
@@ -610,7 +671,7 @@ int mrt_accum_device_ptr(mrt_ctx *c, void **dev_ptr, size_t *bytes)
 {
     if (!c) return fail(MRT_ERR_ARG, "mrt_accum_device_ptr: null context");
     { int rc = set_device(c); if (rc) return rc; if ((rc = settle(c))) return rc; }
-    c->exposed = true;                        // from now on the caller may read the accumulator behind the library's back
+    c->handed_out = true;                     // from now on the caller may read the accumulator behind the library's back (sticky)
     if (dev_ptr) *dev_ptr = c->subs.empty() ? c->d_accum : c->d_full;
     if (bytes) *bytes = (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float);
     ok();
@@ -632,15 +693,15 @@ int mrt_bind_accum(mrt_ctx *c, void *dev_ptr, size_t bytes)
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = settle(c))) return rc;
-    c->exposed = dev_ptr != nullptr;          // the caller reads this memory whenever it likes: every execute runs at once
     const size_t need = (size_t)c->padded_rows * c->pk.nw * 3 * sizeof(float);
     float *dst = dev_ptr ? (float *)dev_ptr : c->d_accum_own;
-    if (dev_ptr && bytes < need) return fail(MRT_ERR_ARG, "mrt_bind_accum: buffer of %zu bytes, need %zu", bytes, need);
+    if (dev_ptr && bytes < need) return fail(MRT_ERR_ARG, "mrt_bind_accum: buffer of %zu bytes, need %zu", bytes, need);     // nothing changed
     if (dst != c->d_accum) {
         HIP_TRY(hipMemcpy(dst, c->d_accum, need, hipMemcpyDeviceToDevice));
         c->d_accum = dst;
         c->P.accum = dst;
     }
+    c->bound = dev_ptr != nullptr;            // only a bind that succeeded: the caller reads this memory whenever it likes, so every execute runs at once
     ok();
     return MRT_OK;
 }
@@ -800,11 +861,11 @@ int mrt_img(mrt_ctx *c, uint8_t *rgb8)
     return MRT_OK;
 }
 
-int mrt_get_stats(const mrt_ctx *c, mrt_stats *out)
+int mrt_get_stats(mrt_ctx *c, mrt_stats *out)
 {
     if (!c || !out) return fail(MRT_ERR_ARG, "mrt_get_stats: null argument");
-    if (c->pending) { int rc = set_device(c); if (rc) return rc; if ((rc = settle(const_cast<mrt_ctx *>(c)))) return rc; }
-    if (c->stats_pending) { const int rc = resolve_stats(const_cast<mrt_ctx *>(c)); if (rc) return rc; }
+    if (c->pending) { int rc = set_device(c); if (rc) return rc; if ((rc = settle(c))) return rc; }      // an observation: booked samples are traced first
+    if (c->stats_pending) { const int rc = resolve_stats(c); if (rc) return rc; }
     *out = c->stats;
     ok();
     return MRT_OK;

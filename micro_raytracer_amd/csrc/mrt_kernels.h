@@ -7,6 +7,7 @@
 namespace mrt {
 
 hipError_t configure_pt(size_t max_lds_bytes);
+u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features);     // FEAT template argument of the kernel launch_pt picks
 size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 features);
 hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 features, hipStream_t stream);
 hipError_t launch_reduce_chunks(float *accum, const float *partial, size_t n_words, size_t stride, u32 n_chunks, hipStream_t stream);

@@ -265,19 +265,41 @@ static void launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Params &
     hipLaunchKernelGGL((pt_megakernel<true, THREADS, FEAT>), grid, dim3(THREADS), lds, stream, P, P.blob);
 }
 
-using LaunchFn = void (*)(dim3, size_t, hipStream_t, const Params &);
-#define MRT_ALL_FEATS(T) { launch_lds<T, 0>, launch_lds<T, 1>, launch_lds<T, 2>, launch_lds<T, 3>, launch_lds<T, 4>, launch_lds<T, 5>, \
-    launch_lds<T, 6>, launch_lds<T, 7>, launch_lds<T, 8>, launch_lds<T, 9>, launch_lds<T, 10>, launch_lds<T, 11>, \
-    launch_lds<T, 12>, launch_lds<T, 13>, launch_lds<T, 14>, launch_lds<T, 15> }
-static const LaunchFn kLds256[16] = MRT_ALL_FEATS(256);
-static const LaunchFn kLds64[16] = MRT_ALL_FEATS(64);
-
 size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 features)
 {
     size_t lds = scene_in_lds ? (size_t)P.lds_words * 4u : 0u;
     if (lds_stash_for(scene_in_lds, (int)block_threads, features)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
     return lds;
 }
+
+// The FEAT template argument of the pt_megakernel instantiation that serves a scene with feature set `features` in a
+// launch shape: the 64- and 256-thread shapes with the scene in LDS exist for every plain feature set; the large
+// shapes (512 / 1024 threads, scene through L2) with and without the triangle / mesh code; the instance-BVH kernels in
+// four feature sets per shape -- plain primitives without / with lights (sphere and plane crowds), everything but
+// triangles and meshes, everything -- of which the smallest covering one runs (a Minecraft-shaped scene without the
+// triangle / mesh code: 113 VGPRs and no scratch instead of 128 + 72 B, +15 %).  Reported in mrt_stats.kernel_features.
+u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
+{
+    constexpr u32 FN = F_ALL & ~F_TRI;
+    const u32 need = features & F_ALL;
+    const u32 big = (need & F_TRI) ? (u32)F_ALL : FN;
+    const u32 nostash = (scene_in_lds && block_threads == 1024u && (features & F_NOSTASH)) ? (u32)F_NOSTASH : 0u;
+    if (features & F_BVH) {
+        if (!scene_in_lds) return big | F_BVH;
+        const u32 pick = (need & (F_BOX | F_TRI | F_MAPS)) == 0 ? (need & F_LIGHTS) : big;
+        return pick | F_BVH | nostash;
+    }
+    if (!scene_in_lds) return big;
+    if (block_threads == 64u || block_threads == 256u) return need;
+    return big | nostash;
+}
+
+#define MRT_CASE(T, F) case (F): launch_lds<T, (F)>(grid, lds, stream, P); return hipGetLastError();
+#define MRT_CASE_L2(F) case (F): hipLaunchKernelGGL((pt_megakernel<false, 256, (F)>), grid, dim3(256), lds, stream, P, P.blob); return hipGetLastError();
+#define MRT_PLAIN16(T) MRT_CASE(T, 0) MRT_CASE(T, 1) MRT_CASE(T, 2) MRT_CASE(T, 3) MRT_CASE(T, 4) MRT_CASE(T, 5) MRT_CASE(T, 6) MRT_CASE(T, 7) \
+    MRT_CASE(T, 8) MRT_CASE(T, 9) MRT_CASE(T, 10) MRT_CASE(T, 11) MRT_CASE(T, 12) MRT_CASE(T, 13) MRT_CASE(T, 14) MRT_CASE(T, 15)
+#define MRT_BVH4(T, X) MRT_CASE(T, F_BVH | (X)) MRT_CASE(T, F_LIGHTS | F_BVH | (X)) MRT_CASE(T, (F_ALL & ~F_TRI) | F_BVH | (X)) MRT_CASE(T, F_ALL | F_BVH | (X))
+#define MRT_BIG2(T, X) MRT_CASE(T, (F_ALL & ~F_TRI) | (X)) MRT_CASE(T, F_ALL | (X))
 
 hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 features, hipStream_t stream)
 {
@@ -289,50 +311,23 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
         grid = dim3((unsigned)(n_wg < P.persist_grid ? n_wg : P.persist_grid), 1, 1);
     }
     const size_t lds = pt_lds_bytes(P, block_threads, scene_in_lds, features);
-    if (features & F_BVH) {
-        // many-instance scenes: per launch shape the BVH kernel comes in four feature sets -- plain primitives without /
-        // with lights (sphere and plane crowds), everything but triangles and meshes, everything -- and the smallest
-        // one that covers the scene runs (a Minecraft-shaped scene without the triangle / mesh code: 113 VGPRs and no
-        // scratch instead of 128 + 72 B, +15 %)
-        const u32 need = features & F_ALL;
-        const u32 pick = (need & (F_BOX | F_TRI | F_MAPS)) == 0 ? (need & F_LIGHTS) : ((need & F_TRI) ? F_ALL : (F_ALL & ~F_TRI));
-#define MRT_BVH_SHAPE(T, EXTRA) \
-        do { \
-            if (pick == 0u) launch_lds<T, F_BVH | EXTRA>(grid, lds, stream, P); \
-            else if (pick == F_LIGHTS) launch_lds<T, F_LIGHTS | F_BVH | EXTRA>(grid, lds, stream, P); \
-            else if (pick == (F_ALL & ~F_TRI)) launch_lds<T, (F_ALL & ~F_TRI) | F_BVH | EXTRA>(grid, lds, stream, P); \
-            else launch_lds<T, F_ALL | F_BVH | EXTRA>(grid, lds, stream, P); \
-        } while (0)
-        if (!scene_in_lds) {
-            if (block_threads != 256u) return hipErrorInvalidConfiguration;
-            if (need & F_TRI) hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL | F_BVH>), grid, dim3(256), lds, stream, P, P.blob);
-            else hipLaunchKernelGGL((pt_megakernel<false, 256, (F_ALL & ~F_TRI) | F_BVH>), grid, dim3(256), lds, stream, P, P.blob);
-        }
-        else if (block_threads == 64u) MRT_BVH_SHAPE(64, 0u);
-        else if (block_threads == 256u) MRT_BVH_SHAPE(256, 0u);
-        else if (block_threads == 512u) MRT_BVH_SHAPE(512, 0u);
-        else if (block_threads == 1024u && (features & F_NOSTASH)) MRT_BVH_SHAPE(1024, F_NOSTASH);
-        else if (block_threads == 1024u) MRT_BVH_SHAPE(1024, 0u);
-        else return hipErrorInvalidConfiguration;
-#undef MRT_BVH_SHAPE
-        return hipGetLastError();
-    }
-    const bool tri = (features & F_TRI) != 0;           // the large shapes come with and without the triangle / mesh code
-    constexpr u32 FN = F_ALL & ~F_TRI;
-    if (scene_in_lds) {
-        if (block_threads == 256u) kLds256[features & F_ALL](grid, lds, stream, P);
-        else if (block_threads == 64u) kLds64[features & F_ALL](grid, lds, stream, P);
-        else if (block_threads == 512u) { if (tri) launch_lds<512, F_ALL>(grid, lds, stream, P); else launch_lds<512, FN>(grid, lds, stream, P); }
-        else if (block_threads == 1024u && (features & F_NOSTASH)) { if (tri) launch_lds<1024, F_ALL | F_NOSTASH>(grid, lds, stream, P); else launch_lds<1024, FN | F_NOSTASH>(grid, lds, stream, P); }
-        else if (block_threads == 1024u) { if (tri) launch_lds<1024, F_ALL>(grid, lds, stream, P); else launch_lds<1024, FN>(grid, lds, stream, P); }
-        else return hipErrorInvalidConfiguration;
-    } else {
+    const u32 inst = pt_instantiation(block_threads, scene_in_lds, features);
+    if (!scene_in_lds) {
         if (block_threads != 256u) return hipErrorInvalidConfiguration;
-        if (tri) hipLaunchKernelGGL((pt_megakernel<false, 256, F_ALL>), grid, dim3(256), lds, stream, P, P.blob);
-        else hipLaunchKernelGGL((pt_megakernel<false, 256, FN>), grid, dim3(256), lds, stream, P, P.blob);
+        switch (inst) { MRT_CASE_L2(F_ALL & ~F_TRI) MRT_CASE_L2(F_ALL) MRT_CASE_L2((F_ALL & ~F_TRI) | F_BVH) MRT_CASE_L2(F_ALL | F_BVH) default: break; }
+    } else if (block_threads == 64u) {
+        switch (inst) { MRT_PLAIN16(64) MRT_BVH4(64, 0u) default: break; }
+    } else if (block_threads == 256u) {
+        switch (inst) { MRT_PLAIN16(256) MRT_BVH4(256, 0u) default: break; }
+    } else if (block_threads == 512u) {
+        switch (inst) { MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) default: break; }
+    } else if (block_threads == 1024u) {
+        switch (inst) { MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) default: break; }
     }
-    return hipGetLastError();
+    return hipErrorInvalidConfiguration;
 }
+#undef MRT_CASE
+#undef MRT_CASE_L2
 
 template <int THREADS, u32 FEAT>
 static hipError_t set_lds_attr(int bytes)
@@ -344,22 +339,13 @@ hipError_t configure_pt(size_t max_lds_bytes)
 {
     const int b = (int)max_lds_bytes;
     hipError_t e;
-#define MRT_SET(F) if ((e = set_lds_attr<256, F>(b)) != hipSuccess) return e; if ((e = set_lds_attr<64, F>(b)) != hipSuccess) return e;
-    MRT_SET(0) MRT_SET(1) MRT_SET(2) MRT_SET(3) MRT_SET(4) MRT_SET(5) MRT_SET(6) MRT_SET(7)
-    MRT_SET(8) MRT_SET(9) MRT_SET(10) MRT_SET(11) MRT_SET(12) MRT_SET(13) MRT_SET(14) MRT_SET(15)
-#undef MRT_SET
-    if ((e = set_lds_attr<1024, F_ALL>(b)) != hipSuccess) return e;
-    if ((e = set_lds_attr<1024, F_ALL & ~F_TRI>(b)) != hipSuccess) return e;
-    if ((e = set_lds_attr<512, F_ALL & ~F_TRI>(b)) != hipSuccess) return e;
-    if ((e = set_lds_attr<1024, (F_ALL & ~F_TRI) | F_NOSTASH>(b)) != hipSuccess) return e;
-    {
-#define MRT_SETB(T, X) if ((e = set_lds_attr<T, F_BVH | X>(b)) != hipSuccess) return e; if ((e = set_lds_attr<T, F_LIGHTS | F_BVH | X>(b)) != hipSuccess) return e; \
-        if ((e = set_lds_attr<T, (F_ALL & ~F_TRI) | F_BVH | X>(b)) != hipSuccess) return e; if ((e = set_lds_attr<T, F_ALL | F_BVH | X>(b)) != hipSuccess) return e;
-        MRT_SETB(64, 0u) MRT_SETB(256, 0u) MRT_SETB(512, 0u) MRT_SETB(1024, 0u) MRT_SETB(1024, F_NOSTASH)
-#undef MRT_SETB
-    }
-    if ((e = set_lds_attr<1024, F_ALL | F_NOSTASH>(b)) != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_megakernel<true, 512, F_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
+#define MRT_CASE(T, F) if ((e = set_lds_attr<T, (F)>(b)) != hipSuccess) return e;
+    MRT_PLAIN16(64) MRT_BVH4(64, 0u)
+    MRT_PLAIN16(256) MRT_BVH4(256, 0u)
+    MRT_BIG2(512, 0u) MRT_BVH4(512, 0u)
+    MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH)
+#undef MRT_CASE
+    return hipSuccess;
 }
 
 hipError_t launch_reduce_chunks(float *accum, const float *partial, size_t n_words, size_t stride, u32 n_chunks, hipStream_t stream)

@@ -13,23 +13,46 @@ namespace mrt {
 class Sampler {
 public:
     // Sampler::new(workers, n_dim), src/sampler.rs:19.  Thread-pool size and tile grid have no GPU meaning.
-    Sampler(uint32_t /*workers*/ = 24, size_t /*n_dim*/ = 64, uint64_t seed = 1, int device = -1) : seed_(seed), device_(device) {}
+    // flags: MRT_FLAG_*; the default is what the Rust shim passes (shim/rust/sampler_hip.rs): no event timing, and
+    // deferred execution -- a per-sample execute() only books its sample, img() / colors() trace what is booked in
+    // 1024-sample batches (same samples, same image; the returned Duration of a booking call is ~0).
+    explicit Sampler(uint32_t /*workers*/ = 24, size_t /*n_dim*/ = 64, uint64_t seed = 1, int device = -1,
+                     uint32_t flags = MRT_FLAG_NO_EVENT_TIMING | MRT_FLAG_DEFER)
+        : seed_(seed), device_(device), flags_(flags) {}
     Sampler(const Sampler &) = delete;
     Sampler &operator=(const Sampler &) = delete;
     ~Sampler() { if (ctx_) mrt_destroy(ctx_); }
 
     // Sampler::execute(&mut self, scene, frame, rt) -> Duration, src/sampler.rs:28: one sample pass.
-    // The context is created on the first call (scene and frame only arrive here), like the Rust shim.
+    // The context is created on the first call (scene and frame only arrive here) and rebuilt when a later call passes
+    // a description with other contents; sums accumulated so far are carried over when the supersampled frame keeps its
+    // size (the reference's map keeps adding whatever the scene, src/sampler.rs:60-70).
     double execute(const mrt_render_desc &render, uint32_t n_samples = 1)
     {
-        if (!ctx_) {
+        const uint64_t print = fingerprint(render);
+        if (!ctx_ || print != print_) {
             mrt_opts o{};
             o.abi_version = MRT_ABI_VERSION;
             o.seed = seed_;
             o.device = device_;
-            ctx_ = mrt_create(&render, &o);
-            if (!ctx_) throw std::runtime_error(mrt_last_error());
-            mrt_dims(ctx_, &nw_, &nh_, nullptr);
+            o.flags = flags_;
+            mrt_ctx *fresh = mrt_create(&render, &o);
+            if (!fresh) throw std::runtime_error(mrt_last_error());
+            uint32_t nw = 0, nh = 0;
+            mrt_dims(fresh, &nw, &nh, nullptr);
+            if (ctx_) {
+                if (nw == nw_ && nh == nh_) {
+                    uint32_t count = 0;
+                    std::vector<float> sums((size_t)nw * nh * 3);
+                    if (mrt_accum(ctx_, sums.data(), &count) != MRT_OK || (count && mrt_set_accum(fresh, sums.data(), count) != MRT_OK)) {
+                        const std::string why = mrt_last_error();
+                        mrt_destroy(fresh);
+                        throw std::runtime_error(why);
+                    }
+                }
+                mrt_destroy(ctx_);
+            }
+            ctx_ = fresh; print_ = print; nw_ = nw; nh_ = nh; ++created_;
             res_w_ = render.frame.res_w; res_h_ = render.frame.res_h;
         }
         double secs = 0;
@@ -55,14 +78,54 @@ public:
         return out;
     }
 
+    mrt_stats stats() const
+    {
+        mrt_stats st{};
+        if (!ctx_ || mrt_get_stats(ctx_, &st) != MRT_OK) throw std::runtime_error(ctx_ ? mrt_last_error() : "stats before execute");
+        return st;
+    }
+
     uint32_t width() const { return res_w_; }
     uint32_t height() const { return res_h_; }
+    uint32_t contexts_created() const { return created_; }
 
 private:
+    // FNV-1a over what the context is built from: every scalar and instance by value; bulk arrays (triangles, texels) by
+    // address, size and a strided sample of their words.
+    struct Fnv {
+        uint64_t h = 1469598103934665603ull;
+        void bytes(const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } }
+        template <class T> void pod(const T &v) { bytes(&v, sizeof v); }
+        void bulk(const float *p, size_t n) { pod(p); pod(n); if (!p) return; const size_t step = 1 + n / 1024; for (size_t i = 0; i < n; i += step) pod(p[i]); }
+    };
+    uint64_t fingerprint(const mrt_render_desc &d)
+    {
+        Fnv f;
+        f.pod(d.rt.bounce); f.pod(d.rt.loss);
+        f.pod(d.frame.res_w); f.pod(d.frame.res_h); f.pod(d.frame.ssaa); f.pod(d.frame.cam.pos); f.pod(d.frame.cam.dir);
+        f.pod(d.frame.cam.fov); f.pod(d.frame.cam.gamma); f.pod(d.frame.cam.exp); f.pod(d.frame.cam.aprt); f.pod(d.frame.cam.foc);
+        f.pod(d.scene.sky.color); f.pod(d.scene.sky.pwr);
+        f.pod(d.scene.n_renderer); f.pod(d.scene.n_light); f.pod(d.scene.n_textures);
+        for (uint32_t i = 0; i < d.scene.n_renderer; ++i) {
+            const mrt_renderer &r = d.scene.renderer[i];
+            f.pod(r.kind); f.pod(r.param); f.pod(r.n_tris); f.pod(r.n_inst);
+            f.pod(r.mat.albedo); f.pod(r.mat.rough); f.pod(r.mat.metal); f.pod(r.mat.glass); f.pod(r.mat.opacity); f.pod(r.mat.emit);
+            f.pod(r.mat.tex); f.pod(r.mat.rmap); f.pod(r.mat.mmap); f.pod(r.mat.gmap); f.pod(r.mat.omap); f.pod(r.mat.emap);
+            if (r.kind == MRT_KIND_MESH) f.bulk(r.tris, (size_t)r.n_tris * 9);
+            for (uint32_t k = 0; k < r.n_inst; ++k) { f.pod(r.inst[k].pos); f.pod(r.inst[k].dir); }
+        }
+        for (uint32_t i = 0; i < d.scene.n_light; ++i) { const mrt_light &l = d.scene.light[i]; f.pod(l.kind); f.pod(l.v); f.pod(l.pwr); f.pod(l.color); }
+        for (uint32_t i = 0; i < d.scene.n_textures; ++i) { const mrt_texture &t = d.scene.textures[i]; f.pod(t.w); f.pod(t.h); f.bulk(t.dat, t.dat ? (size_t)t.w * t.h * 3 : 0); }
+        return f.h;
+    }
+
     mrt_ctx *ctx_ = nullptr;
     uint64_t seed_;
     int device_;
+    uint32_t flags_;
+    uint64_t print_ = 0;
     uint32_t nw_ = 0, nh_ = 0, res_w_ = 0, res_h_ = 0;
+    uint32_t created_ = 0;
 };
 
 // CLI::raytrace / HttpServer::raytrace, src/cli.rs:155-177, src/http.rs:136-148

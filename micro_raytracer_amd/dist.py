@@ -58,10 +58,11 @@ def probe_gather(device=None, group=None) -> bool:
 
 
 def gather_frame(local, nh: int, nw: int, shard_rows: int = DEFAULT_SHARD_ROWS, dst: int = 0, group=None, out=None,
-                 use_all_gather: bool = False):
+                 use_all_gather: bool = False, parts=None):
     """Gather shard accumulators ([padded_rows, nw, 3] f32 tensors, one per rank) to rank `dst` and
     place their rows into the full frame [nh, nw, 3].  Returns the frame on `dst`, None elsewhere.
-    `use_all_gather` (from probe_gather, the same on every rank) selects all_gather for backends without gather."""
+    `use_all_gather` (from probe_gather, the same on every rank) selects all_gather for backends without gather.
+    `parts`: receive buffers (world tensors shaped like the sent one) to reuse instead of allocating them per call."""
     import torch
     import torch.distributed as dist
 
@@ -75,12 +76,13 @@ def gather_frame(local, nh: int, nw: int, shard_rows: int = DEFAULT_SHARD_ROWS, 
     # through host staging copies.
     staged = local.is_cuda and dist.get_backend(group) != "nccl"
     send = local.cpu() if staged else local
-    parts = None
+    if parts is not None:
+        assert len(parts) == world and all(p.shape == send.shape and p.device == send.device for p in parts)
     if use_all_gather:
-        parts = [torch.empty_like(send) for _ in range(world)]
+        parts = parts if parts is not None else [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(parts, send, group=group)
     elif rank == dst:
-        parts = [torch.empty_like(send) for _ in range(world)]
+        parts = parts if parts is not None else [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, gather_list=parts, dst=dst, group=group)
     else:
         dist.gather(send, gather_list=None, dst=dst, group=group)
@@ -129,6 +131,13 @@ class ShardedSampler:
             self.local = self.frame = None       # one rank: the frame stays inside the library (mrt_accum / mrt_img serve it)
         self.count = 0
         self.use_all_gather = probe_gather(self.dev) if world > 1 else False
+        # receive buffers of the gather, allocated once (rank 0, or every rank when all_gather stands in): 7 x 12.4 MB at 4K
+        # per exchange otherwise.  A CPU backend (gloo rehearsals) receives into host memory.
+        self._parts = None
+        if world > 1 and (rank == 0 or self.use_all_gather):
+            import torch.distributed as dist
+            staged = dist.get_backend() != "nccl"
+            self._parts = [torch.empty((pr, self.nw, 3), dtype=torch.float32, device="cpu" if staged else self.dev) for _ in range(world)]
         self.last_gather_ms = 0.0       # wall time of the last exchange on this rank (gather + row placement, synchronised)
 
     def execute(self, n_samples: int = 1, gather: bool = True):
@@ -138,7 +147,8 @@ class ShardedSampler:
         if gather and self.world > 1:
             import time
             t0 = time.perf_counter()
-            gather_frame(self.local, self.nh, self.nw, self.shard_rows, dst=0, out=self.frame, use_all_gather=self.use_all_gather)
+            gather_frame(self.local, self.nh, self.nw, self.shard_rows, dst=0, out=self.frame, use_all_gather=self.use_all_gather,
+                         parts=self._parts)
             if self.world > 1:
                 # like mrt_execute, return only when the exchange is done: the next launch (on the library's own stream)
                 # accumulates into the buffer the collective is still reading

@@ -12,6 +12,7 @@ Rust shim in INTEGRATION.md does.
 from __future__ import annotations
 
 import ctypes as C
+import zlib
 
 import numpy as np
 
@@ -22,15 +23,31 @@ from .scene import Render
 def _fingerprint(render: Render):
     """What the device context was built from, cheap enough to recompute on every execute (the reference's
     Sampler::execute receives scene, frame and rt on every call, src/sampler.rs:28): every scalar and small vector by
-    value; bulk arrays (mesh triangles, texels, long instance lists) by identity and shape."""
+    value; bulk arrays (mesh triangles, texels, long instance lists) by shape, dtype and a CRC of a strided sample of
+    at most ~4 K elements -- an in-place edit of a few elements of a large array between two sample elements is NOT
+    seen (call Sampler.invalidate() after such an edit); anything that replaces, resizes or rewrites the array is.
+    Bulk data that is not an ndarray (a Python list assigned after load_render) is converted and hashed whole on every
+    call: correct, but slow -- keep bulk data as ndarrays, as load_render leaves it."""
     def arr(a):
         if a is None:
             return None
-        a = np.asarray(a)
-        return a.tobytes() if a.size <= 64 else (id(a), a.shape)
+        if not isinstance(a, np.ndarray):
+            a = np.asarray(a)
+            return (a.shape, a.dtype.str, zlib.crc32(a.tobytes()))
+        if a.size <= 64:
+            return a.tobytes()
+        flat = a.reshape(-1)
+        step = max(1, flat.size // 4096)
+        return (a.shape, a.dtype.str, zlib.crc32(np.ascontiguousarray(flat[::step]).tobytes()), zlib.crc32(flat[-16:].tobytes()))
 
     def tex(t):
         return None if t is None else (t.w, t.h, arr(t.dat))
+
+    def insts(lst):
+        if len(lst) <= 16:
+            return tuple((arr(p), arr(d)) for p, d in lst)
+        step = max(1, len(lst) // 64)
+        return (len(lst), tuple((arr(p), arr(d)) for p, d in lst[::step]), arr(lst[-1][0]), arr(lst[-1][1]))
 
     cam = render.frame.cam
     out = [render.rt.bounce, render.rt.loss, tuple(render.frame.res), render.frame.ssaa,
@@ -40,9 +57,8 @@ def _fingerprint(render: Render):
         out.append((l.kind, arr(l.v), l.pwr, arr(l.color)))
     for o in render.scene.renderer:
         m = o.mat
-        inst = tuple((arr(p), arr(d)) for p, d in o.inst) if len(o.inst) <= 16 else (id(o.inst), len(o.inst), arr(o.inst[0][0]), arr(o.inst[-1][0]))
         out.append((o.kind, o.r, arr(o.n), arr(o.sizes), arr(o.vtx), arr(o.mesh), arr(m.albedo), m.rough, m.metal, m.glass,
-                    m.opacity, m.emit, tuple(tex(getattr(m, k)) for k in _abi.MAP_SLOTS), inst))
+                    m.opacity, m.emit, tuple(tex(getattr(m, k)) for k in _abi.MAP_SLOTS), insts(o.inst)))
     return tuple(out)
 
 
@@ -58,6 +74,7 @@ class Sampler:
         self._holder = None
         self._render = None             # strong reference: the context belongs to THIS description (id() of a dead
         self._print = None              # temporary is reused by CPython), and to its contents at creation time
+        self._bound = None              # (device pointer, bytes) of a caller-owned accumulator (bind_accum), re-applied after a rebuild
         self.nw = self.nh = self.local_rows = 0
         self.res = (0, 0)
 
@@ -69,11 +86,21 @@ class Sampler:
         # Another description, or this one edited in place: the device context is rebuilt from what is passed NOW.
         # Like the reference's Sampler, what has been accumulated so far is kept when the supersampled frame keeps
         # its size (src/sampler.rs:60-70 adds into the same map whatever the scene); a different size starts afresh.
+        # A context that owns only some rows (shard_count > 1) or several devices has no entry point that restores
+        # its rows and their sample count, so rebuilding it with samples on board would silently desynchronise the
+        # caller's view (the bound buffer, ShardedSampler.count): that is an error, not a quiet restart.
         carry = None
-        if self._ctx is not None and self.shard_count == 1 and self.n_devices <= 1:
-            old_dims = (self.nw, self.nh)
-            if old_dims == (render.frame.nw, render.frame.nh):
+        bound = self._bound
+        if self._ctx is not None:
+            same_size = (self.nw, self.nh) == (render.frame.nw, render.frame.nh)
+            whole = self.shard_count == 1 and self.n_devices <= 1
+            if not whole and self._count() > 0:
+                raise _lib.MrtError(_abi.MRT_ERR_STATE, "the render description changed under a sharded / multi-device context that "
+                                    "already holds samples: create a new Sampler (or reset() first)")
+            if whole and same_size:
                 carry = self.accum()
+            if not same_size:
+                bound = None                 # the caller's buffer was sized for the old frame
         self.close()
         L = _lib.lib()
         self._holder = _abi.build_desc(render)
@@ -92,14 +119,27 @@ class Sampler:
         _lib.check(L.mrt_dims(ctx, C.byref(nw), C.byref(nh), C.byref(lr)))
         self.nw, self.nh, self.local_rows = nw.value, nh.value, lr.value
         self.res = tuple(render.frame.res)
+        if bound is not None:
+            self.bind_accum(*bound)          # the new context renders into the caller's buffer again (zeroed by the bind)
         if carry is not None and carry[1] > 0:
             self.set_accum(*carry)
+
+    def _count(self) -> int:
+        cnt = C.c_uint32()
+        _lib.check(_lib.lib().mrt_accum(self._ctx, None, C.byref(cnt)))
+        return cnt.value
+
+    def invalidate(self):
+        """Force the next execute to rebuild the device context from the description it is given (after an in-place
+        edit of bulk data the fingerprint cannot see)."""
+        self._print = None
 
     def close(self):
         if self._ctx is not None:
             _lib.lib().mrt_destroy(self._ctx)
             self._ctx = None
         self._render = self._print = None
+        self._bound = None
 
     def __del__(self):
         try:
@@ -174,6 +214,7 @@ class Sampler:
         """Render into caller-owned device memory (a torch tensor's data_ptr()) from now on."""
         self._need()
         _lib.check(_lib.lib().mrt_bind_accum(self._ctx, C.c_void_p(dev_ptr), nbytes))
+        self._bound = (dev_ptr, nbytes) if dev_ptr else None
 
     def set_accum_device(self, dev_ptr, count):
         self._need()

@@ -10,10 +10,16 @@
 // by the C rules repr(C) prescribes and compares every size and field offset with what the C compiler reports for
 // include/mrt.h (tests/native/layout.c) and with the committed table shim/rust/layout.txt.
 //
-// Environment knobs read by the library itself (nothing to do here): MRT_GPUS=N (row-shard over N devices, one RCCL
-// gather per execute), MRT_DEFER=1 (per-sample execute calls only book their sample; the frame is traced in batches
-// when img() observes it -- the per-sample Duration logged at src/cli.rs:164 is then ~0).
+// Per-sample callers: CLI::raytrace and HttpServer::raytrace call execute once per sample (src/cli.rs:162-170,
+// src/http.rs:141-144).  The shim therefore creates its context with MRT_FLAG_DEFER: an execute call only books its
+// sample (the Duration it returns, logged at src/cli.rs:164, is ~0) and the frame is traced in 1024-sample batches
+// when img() observes it -- the batched kernel (7.0 instead of 5.4 Gsamples/s at 1080p) for the unmodified binary; with
+// --update (img() after every sample) this degenerates to the eager loop by itself.  MRT_DEFER=0 in the environment
+// keeps every call synchronous (real per-sample Durations).  Other knobs, read by the library itself: MRT_GPUS=N
+// (row-shard over N devices, one RCCL gather per execute), MRT_SEED (read here).
+use std::collections::hash_map::DefaultHasher;
 use std::ffi::CStr;
+use std::hash::Hasher;
 use std::os::raw::{c_char, c_int};
 use std::time::Duration;
 use image::RgbImage;
@@ -43,24 +49,82 @@ extern "C" {
     fn mrt_destroy(ctx: *mut MrtCtx);
     fn mrt_execute(ctx: *mut MrtCtx, n_samples: u32, seconds: *mut f64) -> c_int;
     fn mrt_img(ctx: *mut MrtCtx, rgb8: *mut u8) -> c_int;
+    fn mrt_dims(ctx: *const MrtCtx, nw: *mut u32, nh: *mut u32, local_rows: *mut u32) -> c_int;
+    fn mrt_accum(ctx: *mut MrtCtx, rgb: *mut f32, count: *mut u32) -> c_int;
+    fn mrt_set_accum(ctx: *mut MrtCtx, rgb: *const f32, count: u32) -> c_int;
     fn mrt_last_error() -> *const c_char;
 }
 
 fn last_error() -> String { unsafe { CStr::from_ptr(mrt_last_error()).to_string_lossy().into_owned() } }
 
-pub struct Sampler { ctx: *mut MrtCtx, seed: u64 }
+pub struct Sampler { ctx: *mut MrtCtx, seed: u64, print: u64 }
 unsafe impl Send for Sampler {}          // one owner at a time, like &mut self (HttpServer: one Sampler per thread)
+
+/// What the device context was built from: execute() receives scene, frame and rt on EVERY call (src/sampler.rs:28), so
+/// a caller may pass something else the next time.  Scalars and instance lists by value, bulk data (mesh triangles,
+/// texels) by address, length and a strided sample -- cheap enough to recompute per call.
+fn fingerprint(scene: &Scene, frame: &Frame, rt: &RayTracer) -> u64 {
+    let mut h = DefaultHasher::new();
+    let mut f = |v: f32| h.write_u32(v.to_bits());
+    let c = &frame.cam;
+    for v in [frame.ssaa, c.pos.x, c.pos.y, c.pos.z, c.dir.w, c.dir.x, c.dir.y, c.dir.z, c.fov, c.gamma, c.exp, c.aprt, c.foc,
+              rt.loss, scene.sky.color.x, scene.sky.color.y, scene.sky.color.z, scene.sky.pwr] { f(v); }
+    let tex = |t: &Option<Texture>, h: &mut DefaultHasher| if let Some(t) = t {
+        h.write_usize(t.w); h.write_usize(t.h);
+        if let Some(d) = &t.dat { h.write_usize(d.as_ptr() as usize); h.write_usize(d.len());
+            for v in d.iter().step_by(1 + d.len() / 256) { h.write_u32(v.x.to_bits()); h.write_u32(v.y.to_bits()); h.write_u32(v.z.to_bits()); } }
+    } else { h.write_u8(0) };
+    drop(f);
+    h.write_u16(frame.res.0); h.write_u16(frame.res.1); h.write_usize(rt.bounce);
+    for obj in scene.renderer.as_deref().unwrap_or(&[]) {
+        let m = &obj.mat;
+        for v in [m.albedo.x, m.albedo.y, m.albedo.z, m.rough, m.metal, m.glass, m.opacity, m.emit] { h.write_u32(v.to_bits()); }
+        for t in [&m.tex, &m.rmap, &m.mmap, &m.gmap, &m.omap, &m.emap] { tex(t, &mut h); }
+        match &obj.kind {
+            RendererKind::Sphere(s) => { h.write_u8(0); h.write_u32(s.0.to_bits()); }
+            RendererKind::Plane(p) => { h.write_u8(1); for v in [p.0.x, p.0.y, p.0.z] { h.write_u32(v.to_bits()); } }
+            RendererKind::Box(b) => { h.write_u8(2); for v in [b.0.x, b.0.y, b.0.z] { h.write_u32(v.to_bits()); } }
+            RendererKind::Triangle(t) => { h.write_u8(3); for v in [t.0.x, t.0.y, t.0.z, t.1.x, t.1.y, t.1.z, t.2.x, t.2.y, t.2.z] { h.write_u32(v.to_bits()); } }
+            RendererKind::Mesh(me) => { h.write_u8(4); h.write_usize(me.mesh.as_ptr() as usize); h.write_usize(me.mesh.len());
+                for t in me.mesh.iter().step_by(1 + me.mesh.len() / 256) { for v in [t.0.x, t.0.y, t.0.z, t.1.x, t.2.x] { h.write_u32(v.to_bits()); } } }
+        }
+        for i in obj.instance.iter() { for v in [i.pos.x, i.pos.y, i.pos.z, i.dir.w, i.dir.x, i.dir.y, i.dir.z] { h.write_u32(v.to_bits()); } }
+    }
+    for l in scene.light.as_deref().unwrap_or(&[]) {
+        let v = match l.kind { LightKind::Point { pos } => (0u8, pos), LightKind::Dir { dir } => (1u8, dir) };
+        h.write_u8(v.0);
+        for x in [v.1.x, v.1.y, v.1.z, l.pwr, l.color.x, l.color.y, l.color.z] { h.write_u32(x.to_bits()); }
+    }
+    h.finish()
+}
 
 impl Sampler {
     pub fn new(_workers: u32, _n_dim: usize) -> Sampler {
         let seed = std::env::var("MRT_SEED").ok().and_then(|s| s.parse().ok())
             .unwrap_or_else(|| rand::random::<u64>());          // the reference is unseeded: default stays random
-        Sampler { ctx: std::ptr::null_mut(), seed }
+        Sampler { ctx: std::ptr::null_mut(), seed, print: 0 }
     }
 
     pub fn execute<'a>(&mut self, scene: &'a Scene, frame: &Frame, rt: &'a RayTracer) -> Duration {
-        if self.ctx.is_null() {
-            self.ctx = create(scene, frame, rt, self.seed).unwrap_or_else(|e| panic!("{e}"));   // reference panics mid-render
+        let print = fingerprint(scene, frame, rt);
+        if self.ctx.is_null() || print != self.print {
+            // first call, or the caller passes another scene / frame / rt than last time: the context is (re)built from what
+            // is passed NOW.  Like the reference, whose map keeps adding whatever the scene (src/sampler.rs:60-70), the sums
+            // accumulated so far are carried over when the supersampled frame keeps its size.
+            let fresh = create(scene, frame, rt, self.seed).unwrap_or_else(|e| panic!("{e}"));   // reference panics mid-render
+            if !self.ctx.is_null() {
+                let (mut ow, mut oh, mut nw, mut nh) = (0u32, 0u32, 0u32, 0u32);
+                unsafe { mrt_dims(self.ctx, &mut ow, &mut oh, std::ptr::null_mut()); mrt_dims(fresh, &mut nw, &mut nh, std::ptr::null_mut()); }
+                if (ow, oh) == (nw, nh) {
+                    let mut sums = vec![0f32; nw as usize * nh as usize * 3];
+                    let mut count = 0u32;
+                    if unsafe { mrt_accum(self.ctx, sums.as_mut_ptr(), &mut count) } != 0 { panic!("{}", last_error()); }
+                    if count > 0 && unsafe { mrt_set_accum(fresh, sums.as_ptr(), count) } != 0 { panic!("{}", last_error()); }
+                }
+                unsafe { mrt_destroy(self.ctx) };
+            }
+            self.ctx = fresh;
+            self.print = print;
         }
         let mut secs = 0f64;
         if unsafe { mrt_execute(self.ctx, 1, &mut secs) } != 0 { panic!("{}", last_error()); }
@@ -70,7 +134,7 @@ impl Sampler {
     pub fn img(&self, frame: &Frame) -> Result<RgbImage, String> {
         if self.ctx.is_null() { return Err("img before execute".into()); }
         let mut buf = vec![0u8; frame.res.0 as usize * frame.res.1 as usize * 3];
-        if unsafe { mrt_img(self.ctx, buf.as_mut_ptr()) } != 0 { return Err(last_error()); }
+        if unsafe { mrt_img(self.ctx, buf.as_mut_ptr()) } != 0 { return Err(last_error()); }     // settles booked samples first
         RgbImage::from_raw(frame.res.0 as u32, frame.res.1 as u32, buf).ok_or("bad image size".to_string())
     }
 }
@@ -128,8 +192,11 @@ fn create(scene: &Scene, frame: &Frame, rt: &RayTracer, seed: u64) -> Result<*mu
             sky: MrtSky { color: [scene.sky.color.x, scene.sky.color.y, scene.sky.color.z], pwr: scene.sky.pwr },
             textures: textures.as_ptr(), n_textures: textures.len() as u32 },
     };
-    // flags: MRT_FLAG_NO_EVENT_TIMING (2) -- this caller runs one sample per call and never reads mrt_stats
-    let opts = MrtOpts { abi_version: 2, seed, device: -1, shard_index: 0, shard_count: 1, shard_rows: 0, n_devices: 0, flags: 2, reserved: [0; 4] };
+    // flags: MRT_FLAG_NO_EVENT_TIMING (2) -- this caller runs one sample per call and never reads mrt_stats -- and
+    // MRT_FLAG_DEFER (4) unless MRT_DEFER=0: per-sample calls book their sample, img() traces them batched
+    let defer = std::env::var("MRT_DEFER").map(|v| v.trim() != "0").unwrap_or(true);
+    let opts = MrtOpts { abi_version: 3, seed, device: -1, shard_index: 0, shard_count: 1, shard_rows: 0, n_devices: 0,
+                         flags: 2 | if defer { 4 } else { 0 }, reserved: [0; 4] };
     let ctx = unsafe { mrt_create(&desc, &opts) };
     if ctx.is_null() { Err(last_error()) } else { Ok(ctx) }
 }

@@ -60,6 +60,24 @@ int main()
         });
         for (auto &x : th) x.join();
         printf("img_threads %016llx %016llx %016llx\n", sums[0], sums[1], sums[2]);
+        // the shim's default (MRT_FLAG_DEFER): per-sample calls are booked, observation traces them; the same loop run
+        // eagerly gives the same image; a changed description rebuilds the context and keeps the sums
+        {
+            mrt::Sampler dfr(24, 64, 7);                                               // default flags: deferred
+            mrt::Sampler eag(24, 64, 7, -1, MRT_FLAG_NO_EVENT_TIMING);
+            for (uint32_t i = 0; i < d.rt.sample; ++i) { dfr.execute(d, 1); eag.execute(d, 1); }
+            const mrt_stats sd = dfr.stats(), se = eag.stats();
+            std::vector<uint8_t> x = dfr.img(), y = eag.img();
+            printf("deferred %u eager %u same %d\n", sd.deferred, se.deferred, (int)(x == y));
+            printf("img_deferred %016llx\n", fnv(x.data(), x.size()));
+            uint32_t c0 = 0, c1 = 0;
+            dfr.colors(&c0);
+            mrt_render_desc d2 = d;
+            d2.rt.bounce = 3;                                                           // another rt on the next call
+            dfr.execute(d2, 1);
+            dfr.colors(&c1);
+            printf("rebuild contexts %u count %u -> %u\n", dfr.contexts_created(), c0, c1);
+        }
         // error path: emit outside [0,1] is what gen_bool would panic on (src/rt.rs:968)
         r.mat.emit = 2.0f;
         try { mrt::Sampler s; s.execute(d, 1); printf("error_path none\n"); }

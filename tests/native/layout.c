@@ -26,6 +26,6 @@ int main(void)
     S(mrt_opts); F(mrt_opts, abi_version); F(mrt_opts, seed); F(mrt_opts, device); F(mrt_opts, shard_index); F(mrt_opts, shard_count); F(mrt_opts, shard_rows);
     F(mrt_opts, n_devices); F(mrt_opts, flags); F(mrt_opts, reserved);
     S(mrt_stats); F(mrt_stats, kernel_ms); F(mrt_stats, gather_ms); F(mrt_stats, samples); F(mrt_stats, segments); F(mrt_stats, launches); F(mrt_stats, lds_bytes);
-    F(mrt_stats, block_threads); F(mrt_stats, scene_bytes); F(mrt_stats, k_split); F(mrt_stats, reserved); F(mrt_stats, img_ms); F(mrt_stats, reduce_ms);
+    F(mrt_stats, block_threads); F(mrt_stats, scene_bytes); F(mrt_stats, k_split); F(mrt_stats, deferred); F(mrt_stats, img_ms); F(mrt_stats, reduce_ms); F(mrt_stats, kernel_features); F(mrt_stats, scene_in_lds);
     return 0;
 }

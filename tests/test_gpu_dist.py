@@ -30,6 +30,27 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert r["gather_ms"] > 0 and 0 < r["kernel_ms_rank_min"] <= r["kernel_ms_rank_max"]
 
 
+def test_bench_many_ranks_rehearsal_of_the_scale_run():
+    """What the driver's SCALE run does, as far as one GPU allows: plain `python bench.py --gpus N` on the headline frame
+    (1920x1080, reduced spp), fresh child processes, every rank on device 0, the gather staged through gloo.  N = 5, not
+    8: the GPU box admits at most 6 processes on its card at once and this pytest process is one of them; the 8-rank
+    frame is covered by tests/test_dist_gloo.py (CPU tensors) and by the in-process shard probe."""
+    n = 5
+    env = dict(os.environ, MRT_DIST_BACKEND="gloo", MRT_SHARE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        env.pop(k, None)                      # bench.py sets HSA_ENABLE_IPC_MODE_LEGACY itself, before importing torch
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--spp", "64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == n and d["steps"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["workload"] == "cornell_1080p_1024spp_b8" and d["config"]["samples_per_step"] == 1920 * 1080 * 64
+    r = d["roofline"]
+    assert r["gather_ms"] > 0 and 0 < r["kernel_ms_rank_min"] <= r["kernel_ms_rank_max"]
+    assert r["pmc_stale"] is False and r["traffic"] is None          # --spp override: nothing is replayed from a profile
+    assert "cpu_baseline" not in d                                    # rank 0 at N = 1 only
+
+
 def test_bench_under_torchrun_still_works():
     """The driver's form: python -m torch.distributed.run ... bench.py --gpus 2."""
     env = dict(os.environ, MRT_DIST_BACKEND="gloo", MRT_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")

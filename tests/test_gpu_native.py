@@ -27,6 +27,10 @@ def test_cpp_sampler_matches_python_sampler_and_is_thread_safe():
     assert kv["updates"] == "4"
     assert kv["img_update"] == kv["img_batched"]                    # per-pass execute == one batched launch
     assert len(set(kv["img_threads"].split())) == 1 and kv["img_threads"].split()[0] == kv["img_update"]
+    # the shim's default flags: per-sample calls booked under MRT_FLAG_DEFER give the eager loop's image, and a changed
+    # description rebuilds the context while the sums are kept (src/sampler.rs:28, 60-70)
+    assert kv["deferred"] == "1 eager 0 same 1" and kv["img_deferred"] == kv["img_update"]
+    assert kv["rebuild"] == "contexts 2 count 4 -> 5"
     assert "emit" in kv["error_path"]                               # Err(String) instead of the reference's panic
     from micro_raytracer_amd import Sampler, scenes
     render, _ = make_holder(scenes.default_scene(res=(96, 54), sample=4))

@@ -384,6 +384,45 @@ def test_deferred_execution_books_calls_and_traces_them_batched():
     assert big.accum()[1] == 0 and not big.accum()[0].any()
 
 
+def test_deferral_stays_off_once_the_device_pointer_was_handed_out(monkeypatch):
+    """A caller that took the raw device pointer (mrt_accum_device_ptr) reads the sums behind the library's back: deferral
+    must stay off for good, also after a bind / un-bind and after a bind that fails; stats.deferred tells which way a call
+    went; MRT_DEFER=0 and an empty MRT_DEFER do not switch deferral on."""
+    import torch
+    from micro_raytracer_amd import Sampler, _abi, scenes
+    from micro_raytracer_amd._lib import MrtError
+    render, _ = make_holder(scenes.cornell_box(res=(64, 48), sample=4))
+    d = Sampler(seed=5, flags=_abi.FLAG_DEFER).create(render)
+    d.execute(render)
+    assert d.stats()["deferred"] == 1
+    ptr, nbytes = d.accum_device_ptr()                   # settles what is booked, then marks the memory as visible
+    with pytest.raises(MrtError):
+        d.bind_accum(ptr, 16)                            # too small: refused, nothing changes
+    d.bind_accum(0, 0)                                   # un-bind: back to library memory, the pointer is still out there
+    d.execute(render, n_samples=3)
+    assert d.stats()["deferred"] == 0
+    seen = torch.empty((48, 64, 3), dtype=torch.float32, device="cuda")
+    import ctypes
+    assert torch.cuda.current_device() == 0
+    # read the device memory directly, as a caller holding the pointer would
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(seen.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(48 * 64 * 12), 3) == 0
+    torch.cuda.synchronize()
+    eager = Sampler(seed=5)
+    eager.execute(render)
+    eager.execute(render, n_samples=3)                   # the same two launches, run at once
+    assert np.array_equal(seen.cpu().numpy().view(np.uint32), eager.accum()[0].view(np.uint32))
+    for val in ("0", ""):
+        monkeypatch.setenv("MRT_DEFER", val)
+        e = Sampler(seed=5)
+        e.execute(render)
+        assert e.stats()["deferred"] == 0
+    monkeypatch.setenv("MRT_DEFER", "1")
+    e = Sampler(seed=5)
+    e.execute(render)
+    assert e.stats()["deferred"] == 1
+
+
 def test_no_event_timing_flag_leaves_kernel_ms_zero():
     from micro_raytracer_amd import Sampler, _abi, scenes
     render, _ = make_holder(scenes.cornell_box(res=(64, 48), sample=4))

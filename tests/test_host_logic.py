@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mrt_abi_version() == 2
+    assert L.mrt_abi_version() == 3
 
 
 def test_no_device_fails_loudly_not_silently():
@@ -271,7 +271,7 @@ class _StubLib:
     """Just enough of libmrt_hip.so to watch which contexts the Python Sampler creates (no GPU here)."""
 
     def __init__(self):
-        self.created, self.destroyed, self.set_accum_calls = [], [], []
+        self.created, self.destroyed, self.set_accum_calls, self.binds = [], [], [], []
         self._next = 1000
         self._count = {}
 
@@ -299,6 +299,10 @@ class _StubLib:
     def mrt_set_accum(self, ctx, rgb, count):
         self.set_accum_calls.append((ctx, count))
         self._count[ctx] = count
+        return 0
+
+    def mrt_bind_accum(self, ctx, ptr, nbytes):
+        self.binds.append((ctx, ptr.value, nbytes))
         return 0
 
     def mrt_last_status(self):
@@ -343,3 +347,56 @@ def test_sampler_context_follows_the_description_not_its_address(monkeypatch):
     assert len(stub.created) == n
     s.close()
     assert len(stub.destroyed) == len(stub.created)
+
+
+def test_sampler_rebuild_keeps_bindings_and_refuses_to_desynchronise_a_shard(monkeypatch):
+    """a rebuilt context must render into the caller's bound buffer again; a sharded context that already
+    holds samples cannot be rebuilt behind the caller's back (its rows and count cannot be restored): that raises."""
+    from micro_raytracer_amd import Sampler, _lib, load_render, scenes
+    from micro_raytracer_amd._lib import MrtError
+    stub = _StubLib()
+    monkeypatch.setattr(_lib, "lib", lambda: stub)
+    r = load_render(scenes.cornell_box(res=(16, 9)))
+    s = Sampler().create(r)
+    s.bind_accum(0xABC000, 16 * 9 * 12)
+    s.execute(r)
+    r.rt.bounce = 2                                                   # in-place edit -> rebuild
+    s.execute(r)
+    assert len(stub.created) == 2
+    assert stub.binds == [(stub.created[0], 0xABC000, 16 * 9 * 12), (stub.created[1], 0xABC000, 16 * 9 * 12)]
+    assert stub.set_accum_calls == [(stub.created[1], 1)]             # and the sums are carried into it
+    s.close()
+    # a shard with samples on board
+    sh = Sampler(shard_index=1, shard_count=2).create(r)
+    sh.bind_accum(0xDEF000, 8 * 16 * 12)
+    r.rt.bounce = 4
+    sh.execute(r)                                                     # nothing accumulated yet: rebuilt and re-bound
+    assert stub.binds[-1] == (stub.created[-1], 0xDEF000, 8 * 16 * 12)
+    n = len(stub.created)
+    r.rt.bounce = 5
+    with pytest.raises(MrtError) as e:
+        sh.execute(r)
+    assert "sharded" in str(e.value) and len(stub.created) == n
+    sh.close()
+
+
+def test_fingerprint_sees_bulk_edits_and_is_stable_for_lists():
+    """Bulk arrays are fingerprinted by shape, dtype and a CRC of a strided sample: rewriting a mesh or a texture is seen,
+    and a mesh assigned as a Python list (a fresh ndarray temporary on every call) does not look changed every time."""
+    from micro_raytracer_amd import load_render, scenes
+    from micro_raytracer_amd.sampler import _fingerprint
+    r = load_render(scenes.mesh_scene(res=(16, 9), n_tris=200))
+    f0 = _fingerprint(r)
+    assert _fingerprint(r) == f0
+    r.scene.renderer[0].mesh *= 1.01                                  # in-place rewrite of every vertex
+    assert _fingerprint(r) != f0
+    f1 = _fingerprint(r)
+    r.scene.renderer[1].mat.tex.dat[::2] = 0.5                        # texels
+    assert _fingerprint(r) != f1
+    r.scene.renderer[0].mesh = r.scene.renderer[0].mesh.tolist()      # a list: converted and hashed whole, stable
+    f2 = _fingerprint(r)
+    assert _fingerprint(r) == f2
+    r2 = load_render(scenes.instance_grid(res=(16, 9), n=4))
+    g0 = _fingerprint(r2)
+    r2.scene.renderer[0].inst[-1][0][0] += 1.0
+    assert _fingerprint(r2) != g0
