@@ -2,6 +2,7 @@
 // of include/mrt.h.  Same three entry points and error behaviour (std::runtime_error <-> Err(String)).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -16,8 +17,15 @@ public:
     // flags: MRT_FLAG_*; the default is what the Rust shim passes (shim/rust/sampler_hip.rs): no event timing, and
     // deferred execution -- a per-sample execute() only books its sample, img() / colors() trace what is booked in
     // 1024-sample batches (same samples, same image; the returned Duration of a booking call is ~0).
+    // MRT_DEFER=0 in the environment keeps the default eager (real per-sample Durations), as in the shim.
+    static uint32_t default_flags()
+    {
+        const char *v = std::getenv("MRT_DEFER");
+        const bool eager = v && v[0] == '0' && v[1] == '\0';
+        return MRT_FLAG_NO_EVENT_TIMING | (eager ? 0u : MRT_FLAG_DEFER);
+    }
     explicit Sampler(uint32_t /*workers*/ = 24, size_t /*n_dim*/ = 64, uint64_t seed = 1, int device = -1,
-                     uint32_t flags = MRT_FLAG_NO_EVENT_TIMING | MRT_FLAG_DEFER)
+                     uint32_t flags = default_flags())
         : seed_(seed), device_(device), flags_(flags) {}
     Sampler(const Sampler &) = delete;
     Sampler &operator=(const Sampler &) = delete;

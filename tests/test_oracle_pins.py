@@ -14,30 +14,48 @@ from conftest import make_holder
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
+def _grid_pin(oracle_mod, desc, pin, spp):
+    """|oracle - reference render| on the pinned sub-sampled grid, for all pixels and for the seed-stable ones.
+
+    The reference is unseeded: its +-0.0005 lens jitter (src/rt.rs:916-920) moves pixels on the sphere silhouette and the
+    highlight between any two of its own runs, so those pixels cannot be pinned by one PNG.  The pixels that do NOT move
+    between two oracle seeds are the ones a seedless reference determines; SURVEY.md App. C's bars (99.9 % / 99.8 % within
+    1 LSB) are asserted on them, and the all-pixel figures are kept as a second, looser assertion."""
+    step = int(pin["step"])
+    imgs = []
+    for seed in (1, 2):
+        _, h = make_holder(desc)
+        o = oracle_mod.Oracle(h, seed=seed)
+        o.execute(spp)
+        imgs.append(o.img()[::step, ::step].astype(int))
+        o.close()
+    d = np.abs(imgs[0] - pin["px"].astype(int))
+    stable = (imgs[0] == imgs[1]).all(axis=2)
+    return d, d[stable], stable.mean()
+
+
 def test_out0_default_scene_deterministic_pin(oracle_mod):
     """doc/out0.png == example/Default.json at 1280x720, 16 spp (README.md:127)."""
     from micro_raytracer_amd import scenes
     pin = np.load(os.path.join(G, "out0_grid.npz"))
-    _, h = make_holder(scenes.default_scene(res=(1280, 720), sample=16))
-    o = oracle_mod.Oracle(h, seed=1)
-    o.execute(16)
-    img = o.img()[:: int(pin["step"]), :: int(pin["step"])]
-    d = np.abs(img.astype(int) - pin["px"].astype(int))
-    assert (d == 0).mean() >= 0.975, (d == 0).mean()
-    assert (d <= 1).mean() >= 0.997, (d <= 1).mean()
+    d, ds, frac = _grid_pin(oracle_mod, scenes.default_scene(res=(1280, 720), sample=16), pin, 16)
+    assert frac >= 0.97, frac                                 # measured 0.987: the jitter touches ~1.3 % of the grid
+    assert (ds <= 1).mean() >= 0.999, (ds <= 1).mean()        # SURVEY App. C: 99.9 % within 1 LSB (measured 99.97 %)
+    assert (ds == 0).mean() >= 0.99, (ds == 0).mean()         # measured 99.4 %
+    assert (d == 0).mean() >= 0.98, (d == 0).mean()           # every grid pixel, jittered ones included: 98.7 % exact,
+    assert (d <= 1).mean() >= 0.998, (d <= 1).mean()          # 99.89 % within 1 LSB
 
 
 def test_out1_ssaa2_lanczos_pin(oracle_mod):
     """doc/out1.png: same scene, 1920x1080 --ssaa 2 (README.md:135): pins tone map + Lanczos3 resize."""
     from micro_raytracer_amd import scenes
     pin = np.load(os.path.join(G, "out1_grid.npz"))
-    _, h = make_holder(scenes.default_scene(res=(1920, 1080), ssaa=2, sample=16))
-    o = oracle_mod.Oracle(h, seed=1)
-    o.execute(2)
-    img = o.img()[:: int(pin["step"]), :: int(pin["step"])]
-    d = np.abs(img.astype(int) - pin["px"].astype(int))
-    assert (d == 0).mean() >= 0.965, (d == 0).mean()
-    assert (d <= 1).mean() >= 0.995, (d <= 1).mean()
+    d, ds, frac = _grid_pin(oracle_mod, scenes.default_scene(res=(1920, 1080), ssaa=2, sample=16), pin, 2)
+    assert frac >= 0.96, frac                                 # measured 0.977
+    assert (ds <= 1).mean() >= 0.998, (ds <= 1).mean()        # SURVEY App. C: 99.8 % within 1 LSB (measured 99.95 %)
+    assert (ds == 0).mean() >= 0.98, (ds == 0).mean()         # measured 98.9 %
+    assert (d == 0).mean() >= 0.97, (d == 0).mean()           # every grid pixel: 97.7 % exact,
+    assert (d <= 1).mean() >= 0.996, (d <= 1).mean()          # 99.76 % within 1 LSB (2 spp here against the render's 16)
 
 
 def _stat_pin(oracle_mod, desc, pin, spp, sb):
