@@ -79,17 +79,19 @@ def cpu_baseline(render, seconds_target=12.0):
     t1 = o.execute(1, threads=1, rows=band)
     single = band_px / t1 / 1e6                             # Msamples/s of ONE thread
     spp_probe = max(1, int(0.5 / t1))                       # ~0.5 s of single-thread work per probe, scaled by the pool
-    best_t, best_rate, probes = 1, single, {1: round(single, 4)}
+    probes = {1: round(single, 4)}
     for t in sorted({min(aff, x) for x in (4, 8, 16, 32, 64, 128, aff)}):
         if t <= 1:
             continue
         n = spp_probe * min(t, 32)
         o.execute(1, threads=t, rows=band)                  # thread creation
         dt = o.execute(n, threads=t, rows=band)
-        rate = band_px * n / dt / 1e6
-        probes[t] = round(rate, 4)
-        if rate > best_rate * 1.03:
-            best_t, best_rate = t, rate
+        probes[t] = round(band_px * n / dt / 1e6, 4)
+    # the smallest pool within 15 % of the fastest: past the container's CPU share more threads only add SMT siblings
+    # and time slicing (first run on the GPU box: 16 threads 5.70, 32 threads 6.37, 256 threads 4.88 Msamples/s)
+    top = max(probes.values())
+    best_t = min(t for t, r in probes.items() if r >= 0.85 * top)
+    best_rate = probes[best_t]
     # the measurement: full-frame passes (n_dim = 64 -> 4096 jobs, join per pass) with the best pool, ~seconds_target
     o.reset()
     frame_px = nh * nw
@@ -100,7 +102,7 @@ def cpu_baseline(render, seconds_target=12.0):
     return {"value": value, "unit": "Msamples/s", "cores": best_t, "threads": best_t, "affinity_cpus": aff, "kind": "port",
             "per_core": value / best_t, "single_thread": single, "pool_probe_Msamples_s": probes,
             "sample": f"{spp} full-frame pass(es) of the {nw}x{nh} frame (n_dim 64: 4096 tile jobs, join per pass), {dt:.1f} s, "
-                      f"{best_t} threads (fastest of the probed pool sizes; {aff} CPUs in the affinity mask)"}
+                      f"{best_t} threads (smallest probed pool within 15 % of the fastest; {aff} CPUs in the affinity mask)"}
 
 
 VALU_ISSUE_PEAK_GINSTR = 1171.0   # G wave-instructions/s of independent v_mul/v_add/v_fma measured on MI355X
