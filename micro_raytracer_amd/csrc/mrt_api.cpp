@@ -256,7 +256,6 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     const size_t all_bytes = (size_t)c->pk.blob.size() * 4;
     if ((e = hipMalloc((void **)&c->d_blob, all_bytes ? all_bytes : 16)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
     if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), all_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
-    const size_t blob_bytes = (size_t)c->pk.P.lds_words * 4;      // the part a workgroup stages in LDS
     {
         const u32 n_blocks = (nh + c->shard_rows - 1) / c->shard_rows;
         c->padded_rows = ((n_blocks + shard_count - 1) / shard_count) * c->shard_rows;
@@ -275,25 +274,40 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     //   64 threads instead when the scene is small enough for ~29 LDS copies per CU (<= 6 KB);
     //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves;
     //   scenes that do not fit the LDS are read through L2.
-    c->scene_in_lds = blob_bytes + 1024 <= kLdsLimit && !getenv("MRT_SCENE_IN_L2");      // env: experiments only
+    // LDS per workgroup = staged scene + lane stash + (mesh kernels) the cooperative walk's slots: pt_lds_bytes knows.
+    // Cold staging (F_COLD): only the hot prefix of the scene -- every table a traversal step reads -- goes to LDS;
+    // triangles, membership tables and texels stay in global memory.  Taken when the whole scene would not leave room for a
+    // 1024-thread workgroup with its stash (MRT_COLD=1 / 0 forces it on / off: experiments, tests).
+    const size_t full_bytes = (size_t)c->pk.P.lds_words * 4;
+    const bool has_cold = c->pk.P.lds_words_hot < c->pk.P.lds_words;
+    c->scene_in_lds = (size_t)c->pk.P.lds_words_hot * 4 + 1024 <= kLdsLimit && !getenv("MRT_SCENE_IN_L2");      // env: experiments only
     const char *force = getenv("MRT_BLOCK_THREADS");      // experiments only
-    u32 want = 256u;
+    auto fits = [&](u32 shape, u32 marker) { return pt_lds_bytes(c->pk.P, shape, true, (c->pk.features & 31u) | marker) <= kLdsLimit; };
+    auto waves = [&](u32 shape, u32 marker) {            // resident wavefronts per CU of this shape, LDS-wise
+        const size_t l = pt_lds_bytes(c->pk.P, shape, true, (c->pk.features & 31u) | marker);
+        return l > kLdsLimit ? (size_t)0 : (shape / 64u) * (kLdsLimit / (l ? l : 1));
+    };
+    u32 cold = 0u;
+    if (c->scene_in_lds && has_cold) {
+        if (const char *f = getenv("MRT_COLD")) cold = atoi(f) ? 64u : 0u;
+        else if (!fits(1024u, 0u)) cold = 64u;
+        if (!cold && full_bytes + 1024 > kLdsLimit) cold = 64u;          // the whole scene does not fit at all
+    }
+    const size_t blob_bytes = c->scene_in_lds ? (size_t)(cold ? c->pk.P.lds_words_hot : c->pk.P.lds_words) * 4 : full_bytes;
+    u32 want = 256u, marker = cold;
     if (c->scene_in_lds) {
-        const size_t w256 = 4u * (kLdsLimit / (blob_bytes + kStash256));
-        const size_t w512 = 8u * (kLdsLimit / (blob_bytes ? blob_bytes : 1));
-        const size_t w1024 = blob_bytes <= kOneCopyStash ? 16u : 0u;
-        if (w256 >= 16u) want = blob_bytes <= kSmallScene ? 64u : 256u;      // single-wave workgroups schedule finest: +1 % on the Cornell scenes at any frame size
+        const size_t w256 = waves(256u, cold), w512 = waves(512u, cold), w1024 = waves(1024u, cold);
+        if (w256 >= 16u) want = (blob_bytes <= kSmallScene && !cold) ? 64u : 256u;      // single-wave workgroups schedule finest: +1 % on the Cornell scenes at any frame size
         else if (w512 >= 16u) want = 512u;
         else if (w1024 >= 16u) want = 1024u;
-        else if (w256 >= w512 && blob_bytes <= kTwoCopies) want = 256u;
-        else { want = 1024u; c->pk.features |= 32u; }      // F_NOSTASH: one LDS copy for 16 waves, lane state in registers
+        else if (w256 >= w512 && w256 >= 8u) want = 256u;
+        else { want = 1024u; marker |= 32u; }      // F_NOSTASH: one LDS copy for 16 waves, lane state in registers
     }
     if (force && c->scene_in_lds) {
         const u32 f = (u32)atoi(force);
-        if ((f == 64u || f == 256u) && blob_bytes <= kTwoCopies) { want = f; c->pk.features &= ~32u; }
-        if (f == 1024u && blob_bytes <= kOneCopyStash) { want = f; c->pk.features &= ~32u; }
-        if (f == 512u) { want = f; c->pk.features &= ~32u; }
+        if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; } }
     }
+    c->pk.features = (c->pk.features & 31u) | marker;
     c->block_threads = want;
     c->pk.P.tiles_x = want == 64u ? 1u : (want == 256u ? 2u : 4u);
     c->pk.P.tiles_y = want == 64u ? 1u : (want == 1024u ? 4u : 2u);
@@ -315,6 +329,9 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         if (per_cu < 1u) per_cu = 1u;
         c->P.persist_grid = c->block_threads > 64u && !getenv("MRT_NO_PERSIST") ? (u32)(n_cu * per_cu) : 0u;
     }
+    c->P.coop_round = kCoopRoundDefault; c->P.coop_split = kCoopSplitDefault;
+    if (const char *f = getenv("MRT_COOP_ROUND")) { const int v = atoi(f); if (v > 0) c->P.coop_round = (u32)v; }        // experiments
+    if (const char *f = getenv("MRT_COOP_SPLIT")) { const int v = atoi(f); if (v > 1) c->P.coop_split = (u32)v; }        // experiments
     c->count_segments = (opts->flags & MRT_FLAG_COUNT_SEGMENTS) != 0;
     c->event_timing = (opts->flags & MRT_FLAG_NO_EVENT_TIMING) == 0;
     c->P.count_segments = c->count_segments ? 1u : 0u;

@@ -49,9 +49,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
 {
     extern __shared__ uint4 lds_blob[];
     const float *F;
+    // words of the scene this workgroup stages: all of it, or (F_COLD) the hot prefix -- records, transforms, materials, node
+    // arrays; triangles, membership tables and texels are then read from global memory
+    const u32 staged_words = !SCENE_IN_LDS ? 0u : ((FEAT & F_COLD) ? P.lds_words_hot : P.lds_words);
     if (SCENE_IN_LDS) {
         const uint4 *g = reinterpret_cast<const uint4 *>(P.blob);
-        const u32 n4 = P.lds_words >> 2;
+        const u32 n4 = staged_words >> 2;
         for (u32 i = threadIdx.x; i < n4; i += blockDim.x) lds_blob[i] = g[i];
         __syncthreads();
         F = reinterpret_cast<const float *>(lds_blob);
@@ -69,6 +72,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
 #endif
     S.G = reinterpret_cast<const float *>(blob_g);
     S.P = &P;
+    // LDS behind the staged scene: [lane stash: ST_SLOTS x blockDim floats] [tbvh_coop: kCoopBytesPerWave per wavefront]
+    constexpr bool kStash = lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS, FEAT);
+    const u32 stash_base4 = (staged_words + 3u) >> 2;                               // in uint4 units, 16-byte aligned
+    S.coop = nullptr;
+    if constexpr (coop_for(FEAT)) {
+        char *base = reinterpret_cast<char *>(lds_blob + stash_base4) + (kStash ? (size_t)ST_SLOTS * BLOCK_THREADS * sizeof(float) : 0u);
+        S.coop = base + (size_t)wave * kCoopBytesPerWave;
+    }
     u32 segments = 0;
     // one 8x8 tile of shard-local rows for this wavefront, lane k of the sample split
     auto do_tile = [&](u32 tx, u32 ty, u32 k) {
@@ -86,7 +97,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
         if constexpr (lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS, FEAT)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
             LdsStash<BLOCK_THREADS> st;
-            st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + (SCENE_IN_LDS ? ((P.lds_words + 3u) >> 2) : 0u)) + threadIdx.x);
+            st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + stash_base4) + threadIdx.x);
             render_pixel<FEAT>(S, st, x, y, job, seg);
         } else {
             RegStash st;
@@ -267,8 +278,11 @@ static void launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Params &
 
 size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 features)
 {
-    size_t lds = scene_in_lds ? (size_t)P.lds_words * 4u : 0u;
-    if (lds_stash_for(scene_in_lds, (int)block_threads, features)) lds = ((lds + 15u) & ~(size_t)15u) + (size_t)ST_SLOTS * block_threads * sizeof(float);
+    const u32 inst = pt_instantiation(block_threads, scene_in_lds, features);      // what the kernel itself sees as FEAT
+    size_t lds = scene_in_lds ? (size_t)((inst & F_COLD) ? P.lds_words_hot : P.lds_words) * 4u : 0u;
+    lds = (lds + 15u) & ~(size_t)15u;
+    if (lds_stash_for(scene_in_lds, (int)block_threads, inst)) lds += (size_t)ST_SLOTS * block_threads * sizeof(float);
+    if (coop_for(inst)) lds += (size_t)(block_threads / 64u) * kCoopBytesPerWave;
     return lds;
 }
 
@@ -283,13 +297,15 @@ u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
     constexpr u32 FN = F_ALL & ~F_TRI;
     const u32 need = features & F_ALL;
     const u32 big = (need & F_TRI) ? (u32)F_ALL : FN;
-    const u32 nostash = (scene_in_lds && block_threads == 1024u && (features & F_NOSTASH)) ? (u32)F_NOSTASH : 0u;
+    const u32 cold = (scene_in_lds && (features & F_COLD)) ? (u32)F_COLD : 0u;       // the cold kernels exist in the big feature sets only
+    const u32 nostash = (scene_in_lds && block_threads == 1024u && (features & F_NOSTASH) && !cold) ? (u32)F_NOSTASH : 0u;
     if (features & F_BVH) {
         if (!scene_in_lds) return big | F_BVH;
         const u32 pick = (need & (F_BOX | F_TRI | F_MAPS)) == 0 ? (need & F_LIGHTS) : big;
-        return pick | F_BVH | nostash;
+        return pick | F_BVH | nostash | cold;
     }
     if (!scene_in_lds) return big;
+    if (cold) return big | cold;
     if (block_threads == 64u || block_threads == 256u) return need;
     return big | nostash;
 }
@@ -318,11 +334,12 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     } else if (block_threads == 64u) {
         switch (inst) { MRT_PLAIN16(64) MRT_BVH4(64, 0u) default: break; }
     } else if (block_threads == 256u) {
-        switch (inst) { MRT_PLAIN16(256) MRT_BVH4(256, 0u) default: break; }
+        switch (inst) { MRT_PLAIN16(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) default: break; }
     } else if (block_threads == 512u) {
-        switch (inst) { MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) default: break; }
+        switch (inst) { MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) default: break; }
     } else if (block_threads == 1024u) {
-        switch (inst) { MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) default: break; }
+        switch (inst) { MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH)
+                        MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) default: break; }
     }
     return hipErrorInvalidConfiguration;
 }
@@ -341,9 +358,9 @@ hipError_t configure_pt(size_t max_lds_bytes)
     hipError_t e;
 #define MRT_CASE(T, F) if ((e = set_lds_attr<T, (F)>(b)) != hipSuccess) return e;
     MRT_PLAIN16(64) MRT_BVH4(64, 0u)
-    MRT_PLAIN16(256) MRT_BVH4(256, 0u)
-    MRT_BIG2(512, 0u) MRT_BVH4(512, 0u)
-    MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH)
+    MRT_PLAIN16(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD)
+    MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD)
+    MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD)
 #undef MRT_CASE
     return hipSuccess;
 }

@@ -503,7 +503,8 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
             mesh_tab.push_back(oc.root == NO_NODE ? NO_NODE : node0 + oc.root);
             mesh_tab.push_back(leaf0);
             mesh_tab.push_back(tb_ok ? tb0 : NO_NODE);
-            mesh_tab.push_back(0); mesh_tab.push_back(0); mesh_tab.push_back(0);
+            mesh_tab.push_back(tb_ok ? tb0 + (u32)(tbn.size() / BVH_WORDS) : 0u);        // MESH_TBVH_END
+            mesh_tab.push_back(0); mesh_tab.push_back(0);
             node_tab.insert(node_tab.end(), oc.nodes.begin(), oc.nodes.end());
             for (u32 id : oc.leaf_ids) leaf_tab.push_back(new_of[id]);
             for (u32 t = 0; t < o.n_tris; ++t) {
@@ -634,12 +635,23 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
         B.f(li.pwr);
         B.f3(h3(li.color[0], li.color[1], li.color[2]));
     }
-    // textures: RGB8 + LUT when every texel is exactly k/255 (what a decoded image file is, src/parser.rs:665)
+    // texture descriptors and the k/255 LUT are hot; the texels themselves are cold (one lookup per shaded hit) and go behind
+    // the node arrays, next to the triangles
     P.off_tex = B.align4();
     const u32 tex_desc0 = (u32)B.w.size();
     B.w.resize(B.w.size() + (size_t)sc.n_textures * TEX_WORDS, 0);
     P.off_lut = B.align4();
     for (int k = 0; k < 256; ++k) B.f((float)k / 255.0f);
+    P.off_mesh = B.align4(); B.w.insert(B.w.end(), mesh_tab.begin(), mesh_tab.end());
+    P.off_node = B.align4(); for (float v : node_tab) B.f(v);
+    P.off_parent = B.align4(); B.w.insert(B.w.end(), parent_tab.begin(), parent_tab.end());
+    P.off_tbvh = B.align4(); for (float v : tbvh_tab) B.f(v);
+    // ---- cold tables (mrt_scene.h Params.lds_words_hot) ----
+    P.lds_words_hot = B.align4();
+    P.off_tri = B.align4(); for (float v : tri_tab) B.f(v);
+    P.off_memb = B.align4(); B.w.insert(B.w.end(), memb_tab.begin(), memb_tab.end());
+    P.off_membe = B.align4(); B.w.insert(B.w.end(), membe_tab.begin(), membe_tab.end());
+    // textures: RGB8 + LUT when every texel is exactly k/255 (what a decoded image file is, src/parser.rs:665)
     for (u32 t = 0; t < sc.n_textures; ++t) {
         const mrt_texture &tx = sc.textures[t];
         u32 *desc = B.w.data() + tex_desc0 + (size_t)t * TEX_WORDS;
@@ -669,13 +681,6 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
             out.n_tex_f32++;
         }
     }
-    P.off_mesh = B.align4(); B.w.insert(B.w.end(), mesh_tab.begin(), mesh_tab.end());
-    P.off_tri = B.align4(); for (float v : tri_tab) B.f(v);
-    P.off_node = B.align4(); for (float v : node_tab) B.f(v);
-    P.off_tbvh = B.align4(); for (float v : tbvh_tab) B.f(v);
-    P.off_memb = B.align4(); B.w.insert(B.w.end(), memb_tab.begin(), memb_tab.end());
-    P.off_membe = B.align4(); B.w.insert(B.w.end(), membe_tab.begin(), membe_tab.end());
-    P.off_parent = B.align4(); B.w.insert(B.w.end(), parent_tab.begin(), parent_tab.end());
     // the octree leaf lists come last: they are not staged in LDS (only rays the TBVH cannot cull read them)
     P.off_leaf = B.align4(); B.w.insert(B.w.end(), leaf_tab.begin(), leaf_tab.end());
     P.lds_words = P.off_leaf;

@@ -61,8 +61,8 @@ enum : u32 { TEX_W = 0, TEX_H = 1, TEX_OFF = 2, TEX_FMT = 3 };
 enum : u32 { TEXFMT_NONE = 0, TEXFMT_F32 = 1, TEXFMT_U8 = 2 };
 
 // MESH: [0] first triangle [1] triangle count [2] root node (0xffffffff: no octree) [3] leaf-id base
-//       [4] root node of the triangle BVH (0xffffffff: none)
-enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4 };
+//       [4] root node of the triangle BVH (0xffffffff: none)  [5] one past its last node (the mesh's nodes are contiguous)
+enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4, MESH_TBVH_END = 5 };
 constexpr u32 NO_NODE = 0xffffffffu;
 
 // NODE: [0..2] 0.5*aabb  [3..5] rel_pos  [6] first child node | first leaf id  [7] count | leaf<<31
@@ -121,8 +121,13 @@ struct Params {
     u32 blob_words;
     u32 lds_words;            // words a workgroup stages in LDS: everything before the octree leaf lists when every mesh has a
                               // triangle BVH (the lists are then only read, from global memory, by rays that cannot be culled)
+    u32 lds_words_hot;        // the hot prefix of that: every table a traversal step reads (records, transforms, materials, all
+                              // node arrays, the texel LUT).  Triangles, the membership tables and the texels follow it and are
+                              // touched at most a few times per path segment: a kernel built with F_COLD stages only the hot
+                              // prefix and reads them from global memory (L2), which frees their LDS for more resident wavefronts
     u32 tiles_x, tiles_y;    // 8x8-pixel wave tiles per workgroup in x and y
     u32 count_segments;
+    u32 coop_round, coop_split;   // tbvh_coop (mrt_trace.h): box steps per round, smallest node span a lane gives away
     // device pointers
     const u32 *blob;
     float *accum;            // [local_rows][nw][3]

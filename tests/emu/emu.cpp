@@ -35,6 +35,20 @@ int emu_pack(const mrt_render_desc *d, uint32_t *blob_words, uint32_t *nw, uint3
     return 0;
 }
 
+// word offsets of the packed tables (mrt_scene.h Params.off_*), in blob order, + lds_words and blob_words: layout tests
+int emu_layout(const mrt_render_desc *d, uint32_t *out /*[32]*/)
+{
+    Packed pk;
+    const int rc = pack_scene(d, pk, g_err);
+    if (rc) return rc;
+    const Params &P = pk.P;
+    const uint32_t v[] = {P.off_rend, P.off_cam, P.off_lin, P.off_bvh, P.off_bvhinst, P.off_inst, P.off_instx, P.off_xf, P.off_mat, P.off_light, P.off_tex,
+                          P.off_lut, P.off_mesh, P.off_node, P.off_parent, P.off_tbvh, P.off_tri, P.off_memb, P.off_membe, P.off_leaf, P.lds_words, P.blob_words,
+                          pk.n_tbvh_nodes, pk.n_nodes, pk.n_tris, pk.n_leaf_ids, pk.n_bvh_nodes, pk.features, P.lds_words_hot};
+    for (size_t i = 0; i < sizeof v / sizeof v[0]; ++i) out[i] = v[i];
+    return 0;
+}
+
 int emu_features(const mrt_render_desc *d)
 {
     Packed pk;
@@ -171,9 +185,9 @@ int emu_mesh_probe(const mrt_render_desc *d, uint32_t n, const float *orig, cons
             const float dd = route == 0 ? ray.dd : __builtin_nanf("");
             float t0 = 0, t1 = 0; i32 i0 = -1, i1 = -1;
             const V3 ro = add(pos, sub(ray.o, pos));
-            const bool h = mesh_isect<false>(S, 0, ro, ray.d, dd, ray.m, pos, t0, i0, t1, i1);
+            const bool h = mesh_isect<false, F_ALL>(S, 0, ro, ray.d, dd, ray.m, pos, t0, i0, t1, i1);
             float u0 = 0, u1 = 0; i32 j0 = -1, j1 = -1;
-            anyq[route] = mesh_isect<true>(S, 0, ro, ray.d, dd, ray.m, pos, u0, j0, u1, j1);
+            anyq[route] = mesh_isect<true, F_ALL>(S, 0, ro, ray.d, dd, ray.m, pos, u0, j0, u1, j1);
             r[route][0] = h; r[route][1] = h ? f2u(t0) : 0; r[route][2] = h ? (u32)i0 : 0; r[route][3] = h ? f2u(t1) : 0; r[route][4] = h ? (u32)i1 : 0;
         }
         if (r[0][0]) ++hits;

@@ -44,6 +44,20 @@ def pack(holder):
     return d
 
 
+LAYOUT_KEYS = ("rend", "cam", "lin", "bvh", "bvhinst", "inst", "instx", "xf", "mat", "light", "tex", "lut", "mesh", "node", "parent", "tbvh",
+               "tri", "memb", "membe", "leaf", "lds_words", "blob_words", "n_tbvh_nodes", "n_nodes", "n_tris", "n_leaf_ids", "n_bvh_nodes", "features",
+               "lds_words_hot")
+
+
+def layout(holder):
+    """Word offsets of the packed tables in blob order + sizes (csrc/mrt_scene.h)."""
+    out = (C.c_uint32 * 32)()
+    rc = lib().emu_layout(C.cast(holder.ptr(), C.c_void_p), out)
+    if rc:
+        raise ValueError((rc, lib().emu_error().decode()))
+    return dict(zip(LAYOUT_KEYS, list(out)))
+
+
 def render(holder, seed, n_samples, sample_base=0, rows=None, threads=8, accum=None):
     L = lib()
     info = pack(holder)
