@@ -47,6 +47,9 @@ WORKLOADS = {
     "c4_cornell2_2160p_1024spp_b16": (dict(kind="cornell_box2", res=(3840, 2160), ssaa=1, bounce=16), 1024),
     "c5_mesh_1080p_512spp": (dict(kind="mesh_scene", res=(1920, 1080), ssaa=1, bounce=8), 512),
     "c5_minecraft_1080p_ssaa2_512spp": (dict(kind="minecraft_like", res=(1920, 1080), ssaa=2, bounce=8), 512),
+    # meshes the LDS cannot hold (any mesh size is legal input, src/parser.rs:805-824): the Mesh.json scene around 5120 / 20480 triangles
+    "mesh5k_1080p_64spp": (dict(kind="mesh_scene", res=(1920, 1080), ssaa=1, bounce=8, n_tris=5120), 64),
+    "mesh20k_540p_64spp": (dict(kind="mesh_scene", res=(960, 540), ssaa=1, bounce=8, n_tris=20480), 64),
 }
 
 

@@ -268,42 +268,93 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipMalloc((void **)&c->d_segments, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);   // + tile counter
     if ((e = hipMemset(c->d_segments, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
 
-    // launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
-    // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most.
+    // ---- what is staged in LDS, and the launch shape -------------------------------------------------------------------
+    // LDS per workgroup = staged scene + lane stash (+ the mesh kernels' leaf queues): pt_lds_bytes knows.  Staging levels:
+    //   all     the whole packed scene (minus the octree leaf lists);
+    //   warm    F_COLD: membership tables and texels stay in global memory (touched at most once per shaded hit); the mesh
+    //           kernels spend the freed LDS on a per-lane leaf queue, so a mesh scene prefers this level when it fits;
+    //   deep    F_COLD | F_DEEP: meshes beyond the LDS.  The scene is packed again with the triangle-BVH table in level order
+    //           and as many of its first nodes -- the top levels of every tree -- as fit next to the small tables are staged;
+    //           deeper nodes and the triangles are read from global memory too;
+    //   none    everything through L2 (the small tables themselves do not fit).
+    // Launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
+    // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most:
     //   256 threads (2x2 wave tiles of 8x8 pixels) + 10 KB lane stash per copy of the scene;
     //   64 threads instead when the scene is small enough for ~29 LDS copies per CU (<= 6 KB);
-    //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves;
-    //   scenes that do not fit the LDS are read through L2.
-    // LDS per workgroup = staged scene + lane stash + (mesh kernels) the cooperative walk's slots: pt_lds_bytes knows.
-    // Cold staging (F_COLD): only the hot prefix of the scene -- every table a traversal step reads -- goes to LDS;
-    // triangles, membership tables and texels stay in global memory.  Taken when the whole scene would not leave room for a
-    // 1024-thread workgroup with its stash (MRT_COLD=1 / 0 forces it on / off: experiments, tests).
-    const size_t full_bytes = (size_t)c->pk.P.lds_words * 4;
-    const bool has_cold = c->pk.P.lds_words_hot < c->pk.P.lds_words;
-    c->scene_in_lds = (size_t)c->pk.P.lds_words_hot * 4 + 1024 <= kLdsLimit && !getenv("MRT_SCENE_IN_L2");      // env: experiments only
-    const char *force = getenv("MRT_BLOCK_THREADS");      // experiments only
-    auto fits = [&](u32 shape, u32 marker) { return pt_lds_bytes(c->pk.P, shape, true, (c->pk.features & 31u) | marker) <= kLdsLimit; };
+    //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves.
+    // Environment (experiments, tests; read here, once): MRT_COLD=0/1 forbids / forces the warm level, MRT_DEEP_NODES=n forces
+    // the deep level with n staged nodes, MRT_SCENE_IN_L2 forces none, MRT_BLOCK_THREADS forces a workgroup size.
+    const bool no_lds = getenv("MRT_SCENE_IN_L2") != nullptr;
+    const char *force = getenv("MRT_BLOCK_THREADS");
+    const bool mesh_walk = c->pk.n_tbvh_nodes != 0u && (c->pk.features & 3u) == 3u;
+    auto lds_of = [&](u32 shape, u32 marker) { return pt_lds_bytes(c->pk.P, shape, true, (c->pk.features & 31u) | marker); };
+    auto fits = [&](u32 shape, u32 marker) { return lds_of(shape, marker) <= kLdsLimit; };
+    auto fits_any = [&](u32 marker) { return fits(256u, marker) || fits(512u, marker) || fits(1024u, marker); };
     auto waves = [&](u32 shape, u32 marker) {            // resident wavefronts per CU of this shape, LDS-wise
-        const size_t l = pt_lds_bytes(c->pk.P, shape, true, (c->pk.features & 31u) | marker);
+        const size_t l = lds_of(shape, marker);
         return l > kLdsLimit ? (size_t)0 : (shape / 64u) * (kLdsLimit / (l ? l : 1));
     };
+    constexpr u32 kWarm = 64u, kDeep = 64u | 128u;       // F_COLD, F_COLD | F_DEEP
+    const bool has_warm = c->pk.P.lds_words_warm < c->pk.P.lds_words;
     u32 cold = 0u;
-    if (c->scene_in_lds && has_cold) {
-        if (const char *f = getenv("MRT_COLD")) cold = atoi(f) ? 64u : 0u;
-        else if (!fits(1024u, 0u)) cold = 64u;
-        if (!cold && full_bytes + 1024 > kLdsLimit) cold = 64u;          // the whole scene does not fit at all
+    bool in_lds = !no_lds;
+    if (in_lds) {
+        const char *fc = getenv("MRT_COLD");
+        const char *fd = getenv("MRT_DEEP_NODES");
+        const bool warm_ok = has_warm && fits_any(kWarm) && !(fc && !atoi(fc));
+        const bool all_ok = fits_any(0u) && !(fc && atoi(fc) && warm_ok);
+        // a mesh scene takes the warm level when a 16-wave workgroup fits with stash and leaf queues (closest-hit walks in one
+        // round: +18 % on the 967-triangle bench scene); everything else takes the whole scene when it fits
+        if (fd && mesh_walk) cold = kDeep;
+        else if (mesh_walk && warm_ok && fits(1024u, kWarm)) cold = kWarm;
+        else if (all_ok) cold = 0u;
+        else if (warm_ok) cold = kWarm;
+        else if (mesh_walk) cold = kDeep;
+        else in_lds = false;
+        if (cold == kDeep) {
+            const size_t stash1024 = (size_t)(ST_SLOTS + 8u) * 1024u * sizeof(float);         // lane stash + leaf queues of one 1024-thread workgroup
+            PackOpts po; po.tbvh_level_order = true;
+            Packed again; std::string err2;
+            bool ok2 = pack_scene(desc, again, err2, po) == MRT_OK && again.tbvh_level_order;
+            const size_t front = ok2 ? (size_t)again.P.off_tbvh * 4 : 0;                         // everything hot in front of the node table
+            ok2 = ok2 && front + stash1024 + 1024 < kLdsLimit;
+            if (ok2) {
+                const size_t room = (kLdsLimit - stash1024 - 1024 - front) / (BVH_WORDS * 4);
+                size_t n = fd ? (size_t)strtoul(fd, nullptr, 10) : room;
+                if (n > room) n = room;
+                if (n > again.n_tbvh_nodes) n = again.n_tbvh_nodes;
+                const u32 n_mesh = (again.P.off_node - again.P.off_mesh) / MESH_WORDS;
+                ok2 = n >= n_mesh && n_mesh > 0u;            // every root is staged (the walk reads it from LDS unconditionally)
+                if (ok2) {
+                    const u32 keep = c->pk.features;
+                    c->pk = again;
+                    c->pk.features = keep;
+                    c->pk.P.n_tbvh_hot = (u32)n;
+                    c->pk.P.lds_words_hot = (c->pk.P.off_tbvh + (u32)n * BVH_WORDS + 3u) & ~3u;
+                    // the blob on the device is the one packed first: replace it
+                    (void)hipFree(c->d_blob); c->d_blob = nullptr;
+                    const size_t bytes2 = (size_t)c->pk.blob.size() * 4;
+                    if ((e = hipMalloc((void **)&c->d_blob, bytes2)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
+                    if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), bytes2, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
+                }
+            }
+            if (!ok2) { cold = 0u; in_lds = false; }
+        }
     }
-    const size_t blob_bytes = c->scene_in_lds ? (size_t)(cold ? c->pk.P.lds_words_hot : c->pk.P.lds_words) * 4 : full_bytes;
+    c->scene_in_lds = in_lds;
+    const size_t full_bytes = (size_t)c->pk.P.lds_words * 4;
+    const size_t blob_bytes = in_lds ? (size_t)staged_words_for(c->pk.P, cold) * 4 : full_bytes;
     u32 want = 256u, marker = cold;
-    if (c->scene_in_lds) {
+    if (in_lds) {
         const size_t w256 = waves(256u, cold), w512 = waves(512u, cold), w1024 = waves(1024u, cold);
         if (w256 >= 16u) want = (blob_bytes <= kSmallScene && !cold) ? 64u : 256u;      // single-wave workgroups schedule finest: +1 % on the Cornell scenes at any frame size
         else if (w512 >= 16u) want = 512u;
         else if (w1024 >= 16u) want = 1024u;
         else if (w256 >= w512 && w256 >= 8u) want = 256u;
-        else { want = 1024u; marker |= 32u; }      // F_NOSTASH: one LDS copy for 16 waves, lane state in registers
+        else if (!cold && fits(1024u, 32u)) { want = 1024u; marker |= 32u; }      // F_NOSTASH: one LDS copy for 16 waves, lane state in registers
+        else want = w1024 ? 1024u : (w512 ? 512u : 256u);
     }
-    if (force && c->scene_in_lds) {
+    if (force && in_lds) {
         const u32 f = (u32)atoi(force);
         if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; } }
     }
@@ -329,9 +380,6 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         if (per_cu < 1u) per_cu = 1u;
         c->P.persist_grid = c->block_threads > 64u && !getenv("MRT_NO_PERSIST") ? (u32)(n_cu * per_cu) : 0u;
     }
-    c->P.coop_round = kCoopRoundDefault; c->P.coop_split = kCoopSplitDefault;
-    if (const char *f = getenv("MRT_COOP_ROUND")) { const int v = atoi(f); if (v > 0) c->P.coop_round = (u32)v; }        // experiments
-    if (const char *f = getenv("MRT_COOP_SPLIT")) { const int v = atoi(f); if (v > 1) c->P.coop_split = (u32)v; }        // experiments
     c->count_segments = (opts->flags & MRT_FLAG_COUNT_SEGMENTS) != 0;
     c->event_timing = (opts->flags & MRT_FLAG_NO_EVENT_TIMING) == 0;
     c->P.count_segments = c->count_segments ? 1u : 0u;

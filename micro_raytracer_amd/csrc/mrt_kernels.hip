@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
     const float *F;
     // words of the scene this workgroup stages: all of it, or (F_COLD) the hot prefix -- records, transforms, materials, node
     // arrays; triangles, membership tables and texels are then read from global memory
-    const u32 staged_words = !SCENE_IN_LDS ? 0u : ((FEAT & F_COLD) ? P.lds_words_hot : P.lds_words);
+    const u32 staged_words = !SCENE_IN_LDS ? 0u : staged_words_for(P, FEAT);
     if (SCENE_IN_LDS) {
         const uint4 *g = reinterpret_cast<const uint4 *>(P.blob);
         const u32 n4 = staged_words >> 2;
@@ -72,14 +72,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(
 #endif
     S.G = reinterpret_cast<const float *>(blob_g);
     S.P = &P;
-    // LDS behind the staged scene: [lane stash: ST_SLOTS x blockDim floats] [tbvh_coop: kCoopBytesPerWave per wavefront]
+    // behind the staged scene (16-byte aligned): [lane stash: ST_SLOTS x blockDim floats] [leaf queues: kQ x blockDim words]
+    const u32 stash_base4 = (staged_words + 3u) >> 2;
     constexpr bool kStash = lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS, FEAT);
-    const u32 stash_base4 = (staged_words + 3u) >> 2;                               // in uint4 units, 16-byte aligned
-    S.coop = nullptr;
-    if constexpr (coop_for(FEAT)) {
-        char *base = reinterpret_cast<char *>(lds_blob + stash_base4) + (kStash ? (size_t)ST_SLOTS * BLOCK_THREADS * sizeof(float) : 0u);
-        S.coop = base + (size_t)wave * kCoopBytesPerWave;
-    }
+    S.lq = nullptr; S.lq_stride = BLOCK_THREADS;
+    if constexpr (leaf_queue_for(FEAT) != 0u)
+        S.lq = (void *)(reinterpret_cast<float *>(lds_blob + stash_base4) + (kStash ? ST_SLOTS * BLOCK_THREADS : 0u) + threadIdx.x);
     u32 segments = 0;
     // one 8x8 tile of shard-local rows for this wavefront, lane k of the sample split
     auto do_tile = [&](u32 tx, u32 ty, u32 k) {
@@ -279,10 +277,10 @@ static void launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Params &
 size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 features)
 {
     const u32 inst = pt_instantiation(block_threads, scene_in_lds, features);      // what the kernel itself sees as FEAT
-    size_t lds = scene_in_lds ? (size_t)((inst & F_COLD) ? P.lds_words_hot : P.lds_words) * 4u : 0u;
+    size_t lds = scene_in_lds ? (size_t)staged_words_for(P, inst) * 4u : 0u;
     lds = (lds + 15u) & ~(size_t)15u;
     if (lds_stash_for(scene_in_lds, (int)block_threads, inst)) lds += (size_t)ST_SLOTS * block_threads * sizeof(float);
-    if (coop_for(inst)) lds += (size_t)(block_threads / 64u) * kCoopBytesPerWave;
+    lds += (size_t)leaf_queue_for(inst) * block_threads * sizeof(u32);
     return lds;
 }
 
@@ -297,7 +295,8 @@ u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
     constexpr u32 FN = F_ALL & ~F_TRI;
     const u32 need = features & F_ALL;
     const u32 big = (need & F_TRI) ? (u32)F_ALL : FN;
-    const u32 cold = (scene_in_lds && (features & F_COLD)) ? (u32)F_COLD : 0u;       // the cold kernels exist in the big feature sets only
+    u32 cold = (scene_in_lds && (features & F_COLD)) ? (u32)F_COLD : 0u;             // the cold kernels exist in the big feature sets only
+    if (cold && (features & F_DEEP) && (need & F_TRI)) cold |= F_DEEP;               // ... and the deep ones with the mesh code only
     const u32 nostash = (scene_in_lds && block_threads == 1024u && (features & F_NOSTASH) && !cold) ? (u32)F_NOSTASH : 0u;
     if (features & F_BVH) {
         if (!scene_in_lds) return big | F_BVH;
@@ -316,6 +315,7 @@ u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
     MRT_CASE(T, 8) MRT_CASE(T, 9) MRT_CASE(T, 10) MRT_CASE(T, 11) MRT_CASE(T, 12) MRT_CASE(T, 13) MRT_CASE(T, 14) MRT_CASE(T, 15)
 #define MRT_BVH4(T, X) MRT_CASE(T, F_BVH | (X)) MRT_CASE(T, F_LIGHTS | F_BVH | (X)) MRT_CASE(T, (F_ALL & ~F_TRI) | F_BVH | (X)) MRT_CASE(T, F_ALL | F_BVH | (X))
 #define MRT_BIG2(T, X) MRT_CASE(T, (F_ALL & ~F_TRI) | (X)) MRT_CASE(T, F_ALL | (X))
+#define MRT_DEEP2(T) MRT_CASE(T, F_ALL | F_COLD | F_DEEP) MRT_CASE(T, F_ALL | F_BVH | F_COLD | F_DEEP)
 
 hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 features, hipStream_t stream)
 {
@@ -334,12 +334,12 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     } else if (block_threads == 64u) {
         switch (inst) { MRT_PLAIN16(64) MRT_BVH4(64, 0u) default: break; }
     } else if (block_threads == 256u) {
-        switch (inst) { MRT_PLAIN16(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) default: break; }
+        switch (inst) { MRT_PLAIN16(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256) default: break; }
     } else if (block_threads == 512u) {
-        switch (inst) { MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) default: break; }
+        switch (inst) { MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512) default: break; }
     } else if (block_threads == 1024u) {
         switch (inst) { MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH)
-                        MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) default: break; }
+                        MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) MRT_DEEP2(1024) default: break; }
     }
     return hipErrorInvalidConfiguration;
 }
@@ -358,9 +358,9 @@ hipError_t configure_pt(size_t max_lds_bytes)
     hipError_t e;
 #define MRT_CASE(T, F) if ((e = set_lds_attr<T, (F)>(b)) != hipSuccess) return e;
     MRT_PLAIN16(64) MRT_BVH4(64, 0u)
-    MRT_PLAIN16(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD)
-    MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD)
-    MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD)
+    MRT_PLAIN16(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256)
+    MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512)
+    MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) MRT_DEEP2(1024)
 #undef MRT_CASE
     return hipSuccess;
 }

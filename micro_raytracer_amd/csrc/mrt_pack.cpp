@@ -313,7 +313,7 @@ u32 to_usize_u32(float v)   // (res as f32 * ssaa) as usize, src/sampler.rs:29-3
 
 }  // namespace
 
-int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
+int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const PackOpts &opts)
 {
     char msg[256];
     if (!d) { err = "null render description"; return MRT_ERR_ARG; }
@@ -642,13 +642,39 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err)
     B.w.resize(B.w.size() + (size_t)sc.n_textures * TEX_WORDS, 0);
     P.off_lut = B.align4();
     for (int k = 0; k < 256; ++k) B.f((float)k / 255.0f);
+    if (opts.tbvh_level_order && !tbvh_tab.empty()) {
+        // depth-first table (first child = node + 1) -> level order over all meshes, explicit child links
+        const u32 nn = (u32)(tbvh_tab.size() / BVH_WORDS);
+        std::vector<u32> depth(nn, 0), newi(nn, 0), roots;
+        for (size_t k = 0; k + MESH_WORDS <= mesh_tab.size(); k += MESH_WORDS) if (mesh_tab[k + MESH_TBVH] != NO_NODE) roots.push_back(mesh_tab[k + MESH_TBVH]);
+        // children of n (internal): n + 1 and skip(n + 1); depth by one pass in index order (parents precede children)
+        auto skip_of = [&](u32 n) { return bits(tbvh_tab[(size_t)n * BVH_WORDS + BVH_SKIP]); };
+        auto leaf_of = [&](u32 n) { return bits(tbvh_tab[(size_t)n * BVH_WORDS + BVH_LEAF]); };
+        for (u32 n = 0; n < nn; ++n) if (leaf_of(n) == 0u) { depth[n + 1] = depth[n] + 1; depth[skip_of(n + 1)] = depth[n] + 1; }
+        std::vector<u32> order(nn);
+        for (u32 n = 0; n < nn; ++n) order[n] = n;
+        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return depth[a] < depth[b]; });   // siblings stay adjacent-ish: index order within a level
+        for (u32 k = 0; k < nn; ++k) newi[order[k]] = k;
+        std::vector<float> re(tbvh_tab.size());
+        for (u32 n = 0; n < nn; ++n) {
+            float *q = re.data() + (size_t)newi[n] * BVH_WORDS;
+            memcpy(q, tbvh_tab.data() + (size_t)n * BVH_WORDS, BVH_WORDS * sizeof(float));
+            const u32 sk = skip_of(n);
+            q[BVH_SKIP] = fbits(sk == BVH_END ? BVH_END : newi[sk]);
+            if (leaf_of(n) == 0u) q[BVH_LEAF] = fbits(BVH_INTERNAL | newi[n + 1]);
+        }
+        tbvh_tab.swap(re);
+        for (size_t k = 0; k + MESH_WORDS <= mesh_tab.size(); k += MESH_WORDS) if (mesh_tab[k + MESH_TBVH] != NO_NODE) { mesh_tab[k + MESH_TBVH] = newi[mesh_tab[k + MESH_TBVH]]; mesh_tab[k + MESH_TBVH_END] = 0u; }
+        out.tbvh_level_order = true;
+    }
     P.off_mesh = B.align4(); B.w.insert(B.w.end(), mesh_tab.begin(), mesh_tab.end());
     P.off_node = B.align4(); for (float v : node_tab) B.f(v);
     P.off_parent = B.align4(); B.w.insert(B.w.end(), parent_tab.begin(), parent_tab.end());
     P.off_tbvh = B.align4(); for (float v : tbvh_tab) B.f(v);
-    // ---- cold tables (mrt_scene.h Params.lds_words_hot) ----
+    // ---- tables a kernel may leave in global memory (mrt_scene.h Params.lds_words_hot / lds_words_warm) ----
     P.lds_words_hot = B.align4();
     P.off_tri = B.align4(); for (float v : tri_tab) B.f(v);
+    P.lds_words_warm = B.align4();
     P.off_memb = B.align4(); B.w.insert(B.w.end(), memb_tab.begin(), memb_tab.end());
     P.off_membe = B.align4(); B.w.insert(B.w.end(), membe_tab.begin(), membe_tab.end());
     // textures: RGB8 + LUT when every texel is exactly k/255 (what a decoded image file is, src/parser.rs:665)

@@ -16,11 +16,19 @@ struct Packed {
     u32 res_w = 0, res_h = 0;
     float gamma = 0, exp = 0;
     u32 features = 0;            // F_* bits of mrt_trace.h the scene needs
+    bool tbvh_level_order = false;   // the triangle-BVH table is in level order with explicit child links (PackOpts)
     u32 n_tex_u8 = 0, n_tex_f32 = 0, n_nodes = 0, n_leaf_ids = 0, n_tris = 0, n_xf = 0, n_bvh_nodes = 0, n_lin = 0, n_tbvh_nodes = 0;
 };
 
+struct PackOpts {
+    // Triangle BVHs in LEVEL order with explicit child links (mrt_scene.h): the table starts with the top levels of every
+    // mesh, so that a prefix of it -- whatever the LDS has room for -- can be staged while the deeper nodes stay in global
+    // memory (kernels built with F_DEEP).  Default: depth-first order, first child = node + 1 (everything fits the LDS).
+    bool tbvh_level_order = false;
+};
+
 // Returns MRT_OK or an MRT_ERR_* code with a message in err.
-int pack_scene(const mrt_render_desc *desc, Packed &out, std::string &err);
+int pack_scene(const mrt_render_desc *desc, Packed &out, std::string &err, const PackOpts &opts = PackOpts());
 
 // Flattened octree of one mesh in the layout of mrt_scene.h (exposed for tests).
 struct OctreeFlat {

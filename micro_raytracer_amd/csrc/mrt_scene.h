@@ -85,7 +85,12 @@ enum : u32 { NODE_HALF = 0, NODE_REL = 3, NODE_FIRST = 6, NODE_COUNT = 7 };
 //   PARENT (one word per octree node, off_parent + node): parent node, NO_NODE for a root
 // The mesh's triangles are stored in TBVH leaf order; the octree leaf lists hold the permuted ids (a relabelling the
 // reference cannot observe: ids only select a triangle and are compared for equality, src/rt.rs:756).
+// Level-ordered variant of the TBVH table (PackOpts::tbvh_level_order, kernels with F_DEEP): the nodes of ALL meshes sorted
+// by depth (roots first), the leaf word of an internal node = 0x80000000 | index of its first child (the second child is the
+// first one's skip link), skip links unchanged in meaning.  Nodes below Params.n_tbvh_hot are staged in LDS, the rest is
+// read from global memory: the top of every tree, which every walk passes, stays in LDS whatever the size of the meshes.
 constexpr u32 BVH_WORDS = 8;
+constexpr u32 BVH_INTERNAL = 0x80000000u;
 constexpr u32 MEMB_SLOT_BITS = 22u, MEMB_SLOT_MASK = (1u << MEMB_SLOT_BITS) - 1u;
 enum : u32 { BVH_C = 0, BVH_H = 3, BVH_SKIP = 6, BVH_LEAF = 7 };
 constexpr u32 BVH_END = 0xffffffffu;
@@ -118,16 +123,18 @@ struct Params {
                               // need them: kept out of the scalar registers)
     u32 off_rend, off_inst, off_instx, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
     u32 off_tbvh, off_memb, off_membe, off_parent;
+    u32 n_tbvh_hot;           // F_DEEP: triangle-BVH nodes with index < n_tbvh_hot are in LDS (set by mrt_create from the LDS budget)
     u32 blob_words;
     u32 lds_words;            // words a workgroup stages in LDS: everything before the octree leaf lists when every mesh has a
                               // triangle BVH (the lists are then only read, from global memory, by rays that cannot be culled)
-    u32 lds_words_hot;        // the hot prefix of that: every table a traversal step reads (records, transforms, materials, all
-                              // node arrays, the texel LUT).  Triangles, the membership tables and the texels follow it and are
-                              // touched at most a few times per path segment: a kernel built with F_COLD stages only the hot
-                              // prefix and reads them from global memory (L2), which frees their LDS for more resident wavefronts
+    // Shorter staging prefixes of the blob (table order: records, transforms, materials, LUT, node arrays | triangles |
+    // membership tables, texels | leaf lists), for kernels that leave the rarely touched tables in global memory (L2):
+    u32 lds_words_warm;       // F_COLD: everything up to and including the triangles; membership tables (read per triangle HIT) and
+                              // texels (one lookup per shaded hit) stay out -- their LDS goes to the per-lane leaf queue of the mesh walk
+    u32 lds_words_hot;        // F_COLD | F_DEEP: every table a traversal step reads (records ... node arrays); triangles stay out too.
+                              // mrt_create shrinks it to off_tbvh + n_tbvh_hot nodes when not even the node arrays fit
     u32 tiles_x, tiles_y;    // 8x8-pixel wave tiles per workgroup in x and y
     u32 count_segments;
-    u32 coop_round, coop_split;   // tbvh_coop (mrt_trace.h): box steps per round, smallest node span a lane gives away
     // device pointers
     const u32 *blob;
     float *accum;            // [local_rows][nw][3]

@@ -26,18 +26,16 @@ enum : u32 {
     F_ALL = 15u,
     F_BVH = 16u,      // many instances: a BVH over them replaces most of the linear scan (only built with F_ALL)
     F_NOSTASH = 32u,  // launch-shape marker, not a scene feature: 1024-thread workgroup whose scene leaves no LDS for the lane stash
-    F_COLD = 64u      // launch-shape marker: only the hot prefix of the scene is staged in LDS (Params.lds_words_hot); triangles,
-                      // membership tables and texels are read from global memory
+    F_COLD = 64u,     // launch-shape marker: membership tables and texels are read from global memory, not staged in LDS
+                      // (Params.lds_words_warm); the mesh kernels use the freed LDS for a per-lane queue of postponed leaves
+    F_DEEP = 128u     // with F_COLD, meshes beyond the LDS: triangles stay in global memory too (Params.lds_words_hot) and the
+                      // triangle-BVH table is in level order with explicit child links (mrt_scene.h), of which only the first
+                      // Params.n_tbvh_hot nodes -- the top levels of every tree -- are staged
 };
-
-// Wave-cooperative triangle-BVH walk (tbvh_coop below): device code of the mesh kernels without an instance BVH, where every
-// lane of a wavefront meets a mesh instance at the same time.  MRT_NO_COOP builds the per-lane walk everywhere (A/B runs).
-#if defined(__HIPCC__) && !defined(MRT_NO_COOP)       // hipcc, host and device pass alike (the host sizes the LDS for it); not the x86 test build
-constexpr bool kCoopBuild = true;
-#else
-constexpr bool kCoopBuild = false;
-#endif
-constexpr bool coop_for(u32 feat) { return kCoopBuild && (feat & F_TRI) && (feat & F_BOX) && !(feat & F_BVH); }
+// words of the packed scene a kernel instantiation stages in LDS
+MRT_HD u32 staged_words_for(const Params &P, u32 feat) { return (feat & F_DEEP) ? P.lds_words_hot : ((feat & F_COLD) ? P.lds_words_warm : P.lds_words); }
+// entries of the per-lane leaf queue (LDS, behind the lane stash) of the closest-hit mesh walk; 0: no queue, two leaves in registers
+constexpr u32 leaf_queue_for(u32 feat) { return ((feat & F_COLD) && (feat & F_TRI) && (feat & F_BOX)) ? 8u : 0u; }
 
 // Divergence probe: only the x86 build of tests/emu defines MRT_PROBE(phase); in the kernel it is nothing.
 #ifndef MRT_PROBE
@@ -228,16 +226,38 @@ MRT_HD uint64_t to_index(float v)
     return (uint64_t)(u32)v;
 }
 
+#if defined(__HIPCC__) || defined(__HIP__)
+typedef __attribute__((address_space(3))) volatile float lds_vfloat;   // keeps ds_read / ds_write addressing
+#endif
+
 struct Scn {
     const float *F;      // the packed scene (LDS): per-lane (divergent) lookups
     const float *U;      // the same blob for wave-uniform reads of the traversal loop: LDS, or global memory
                          // read through the scalar cache into SGPRs (MRT_UNIFORM_SMEM)
     const float *G;      // the whole blob in global memory (the octree leaf lists are not staged when every mesh has a TBVH)
     const Params *P;
-    void *coop;          // this wavefront's 1280 bytes of LDS for tbvh_coop (result slots + matching scratch), or null
+    void *lq;            // this lane's leaf queue (device: an LDS column, entry e at lq[e * lq_stride]; x86 test build: unused)
+    u32 lq_stride;
 };
-// bytes of LDS one wavefront needs for tbvh_coop: 64 x (u64 min pair, u64 max pair) + 64 x u32 matching scratch
-constexpr u32 kCoopBytesPerWave = 64u * 16u + 64u * 4u;
+
+// The leaf queue of the closest-hit mesh walk: leaf words (count << 24 | first triangle) a lane has found and not tested yet.
+// Device: a per-lane LDS column behind the lane stash (slot-major like the stash: lane i always hits bank i); the x86 test
+// build keeps it in a local array.
+template <u32 Q>
+struct LeafQ {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lds_vfloat *b;
+    u32 stride;
+    MRT_HD explicit LeafQ(const Scn &S) : b((lds_vfloat *)S.lq), stride(S.lq_stride) {}
+    MRT_HD void put(u32 e, u32 v) { b[e * stride] = u2f(v); }
+    MRT_HD u32 get(u32 e) const { return f2u(b[e * stride]); }
+#else
+    u32 v[Q ? Q : 1u];
+    MRT_HD explicit LeafQ(const Scn &) {}
+    MRT_HD void put(u32 e, u32 x) { v[e] = x; }
+    MRT_HD u32 get(u32 e) const { return v[e]; }
+#endif
+};
 
 // Texture::get_color, src/rt.rs:618-628; the flat index is clamped to the last texel where the
 // reference would panic (documented divergence).  Returns all three channels.
@@ -341,7 +361,7 @@ template <bool ANY, u32 FEAT>
 MRT_HD bool mesh_isect_ref(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
 {
     const float *F = S.F;
-    const float *C = (FEAT & F_COLD) ? S.G : S.F;
+    const float *CT = (FEAT & F_DEEP) ? S.G : S.F;
     const Params &P = *S.P;
     const float *M = F + P.off_mesh + mesh * MESH_WORDS;
     const u32 tri0 = ldu(M, MESH_TRI0), ntri = ldu(M, MESH_NTRI), root = ldu(M, MESH_ROOT), leaf0 = ldu(M, MESH_LEAF0);
@@ -351,7 +371,7 @@ MRT_HD bool mesh_isect_ref(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, f
     auto test = [&](u32 id) {
         if (id == last_id) return;          // Vec::dedup (src/rt.rs:756)
         last_id = id;
-        const float *T = C + P.off_tri + (tri0 + id) * TRI_WORDS;
+        const float *T = CT + P.off_tri + (tri0 + id) * TRI_WORDS;
         float t;
         if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t)) return;
         const i32 k = total_key(t);
@@ -393,7 +413,8 @@ template <bool ANY, u32 FEAT>
 MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
 {
     const float *F = S.F;
-    const float *C = (FEAT & F_COLD) ? S.G : S.F;        // triangles and membership tables: cold
+    const float *C = (FEAT & F_COLD) ? S.G : S.F;        // membership tables: cold
+    const float *CT = (FEAT & F_DEEP) ? S.G : S.F;       // triangles: cold only for meshes beyond the LDS
     const Params &P = *S.P;
     const float *M = F + P.off_mesh + mesh * MESH_WORDS;
     const u32 tri0 = ldu(M, MESH_TRI0), root = ldu(M, MESH_ROOT);
@@ -415,7 +436,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
         const CullRay R = cull_ray(ol, rd);
         V3 oinv, qm;
         {
-            const F4 ra = ld4(B0, tb * BVH_WORDS), rb = ld4(B0, tb * BVH_WORDS + 4);
+            const F4 ra = ld4(B0, tb * BVH_WORDS), rb = ld4(B0, tb * BVH_WORDS + 4);      // (a root is always among the staged nodes)
             const V3 c = v3(ra.x, ra.y, ra.z), hh = v3(ra.w, rb.x, rb.y);
             const float big = fmax_(fmax_(fabs_(pos.x), fabs_(pos.y)), fabs_(pos.z)) + fmax_(fmax_(fabs_(c.x) + hh.x, fabs_(c.y) + hh.y), fabs_(c.z) + hh.z)
                               + fmax_(fmax_(fabs_(ol.x), fabs_(ol.y)), fabs_(ol.z));
@@ -425,6 +446,81 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
         }
         u32 s0 = 0, s1 = 0;
         u32 node = tb;
+        if constexpr (!ANY && leaf_queue_for(FEAT) != 0u) {
+            // Closest-hit walk with EVERY leaf postponed: the box walk runs on until the tree is exhausted (or the lane's queue
+            // of kQ leaves is full), then the exact tests of all queued leaves run together, one triangle per lane per trip.
+            // A wavefront pays, per round, the longest box walk and the longest triangle list of its lanes: with two leaves
+            // per round (below) that is 76 box steps + 12 triangle tests per loop iteration on the 967-triangle bench mesh,
+            // with one round per walk 46 + 11 (tests/emu/round_probe.cpp).  Shadow queries keep the two-leaf rounds: their
+            // first candidate ends the walk.  The candidate set, and with it the answer, is the same in any order.
+            constexpr u32 kQ = leaf_queue_for(FEAT);
+            LeafQ<kQ> q(S);
+            for (;;) {
+                u32 nq = 0u;
+                u32 probe_steps = 0; (void)probe_steps;
+                bool walking = node != BVH_END;
+                while (walking) {
+                    ++probe_steps;
+                    F4 na, nb;
+                    if constexpr (FEAT & F_DEEP) {
+                        if (node < P.n_tbvh_hot) { na = ld4(B0, node * BVH_WORDS); nb = ld4(B0, node * BVH_WORDS + 4); }
+                        else { const float *BG = S.G + P.off_tbvh; na = ld4(BG, node * BVH_WORDS); nb = ld4(BG, node * BVH_WORDS + 4); }
+                    } else { na = ld4(B0, node * BVH_WORDS); nb = ld4(B0, node * BVH_WORDS + 4); }
+                    MRT_COUNT(CT_TBVH_NODE);
+                    const u32 skip = f2u(nb.z);
+                    u32 leaf = f2u(nb.w), child = node + 1u;
+                    if constexpr (FEAT & F_DEEP) { child = leaf & ~BVH_INTERNAL; leaf = (leaf & BVH_INTERNAL) ? 0u : leaf; }
+                    const float px = fma_fast(na.x, R.inv.x, -oinv.x), py = fma_fast(na.y, R.inv.y, -oinv.y), pz = fma_fast(na.z, R.inv.z, -oinv.z);
+                    const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);
+                    const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
+                    const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
+                    const bool hit = !(tn > tf || tf < 0.0f);
+                    q.put(nq, leaf);                                   // branch-free: the slot only counts when the leaf was hit
+                    nq += (hit && leaf != 0u) ? 1u : 0u;
+                    node = (hit && leaf == 0u) ? child : skip;
+                    walking = node != BVH_END && nq < kQ;
+                }
+                if (nq == 0u) { MRT_PROBE_ROUND(probe_steps, 0u, 0u); break; }
+                u32 e = 0u, j = 0u, leaf = q.get(0u), probe_tris = 0; (void)probe_tris;
+                while (e < nq) {
+                    const u32 id = (leaf & 0xffffffu) + j;
+                    ++j; ++probe_tris;
+                    if (j == (leaf >> 24)) { ++e; j = 0u; if (e < nq) leaf = q.get(e); }
+                    const float *T = CT + P.off_tri + (tri0 + id) * TRI_WORDS;
+                    float t;
+                    MRT_COUNT(CT_TBVH_TRI);
+                    if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t)) continue;
+                    MRT_COUNT(CT_TBVH_TRI_HIT);
+                    const u32 head = ldu(C, P.off_memb + tri0 + id);
+                    const u32 e0 = head & 0xffffffu, ne = head >> 24;
+                    u32 sl = 0xffffffffu, sh = 0u;
+                    bool cand = false;
+                    for (u32 k = 0; k < ne; ++k) {
+                        const u32 w = ldu(C, P.off_membe + e0 + k);
+                        u32 n = root + (w >> MEMB_SLOT_BITS);
+                        bool reached = true;
+                        while (n != root) {
+                            MRT_COUNT(CT_MEMB_BOX);
+                            if (!box_isect(ld3(N0, n * NODE_WORDS + NODE_HALF), ro, m, add(pos, ld3(N0, n * NODE_WORDS + NODE_REL)), a0, a1)) { reached = false; break; }
+                            n = ldu(F, P.off_parent + n);
+                        }
+                        if (!reached) continue;
+                        const u32 slot = w & MEMB_SLOT_MASK;    // entries are in slot order
+                        if (!cand) sl = slot;
+                        sh = slot;
+                        cand = true;
+                    }
+                    if (!cand) continue;
+                    const i32 k = total_key(t);
+                    if (!any) { any = true; t0 = t1 = t; i0 = i1 = (i32)id; k0 = k1 = k; s0 = sl; s1 = sh; continue; }
+                    if (k < k0 || (k == k0 && sl < s0)) { k0 = k; s0 = sl; t0 = t; i0 = (i32)id; }      // min_by: first minimum, src/rt.rs:764
+                    if (k > k1 || (k == k1 && sh > s1)) { k1 = k; s1 = sh; t1 = t; i1 = (i32)id; }      // max_by: last maximum, src/rt.rs:765
+                }
+                MRT_PROBE_ROUND(probe_steps, probe_tris, 0u);
+                if (node == BVH_END) break;
+            }
+            return any;
+        }
         // "while-while" with one postponed leaf: a lane walks boxes until it has found two leaves (or the end), then the
         // wavefront runs the exact triangle tests of both together -- fewer, fuller rounds than one leaf at a time.
         for (;;) {
@@ -435,10 +531,16 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             bool walking = node != BVH_END;
             while (walking) {
                 ++probe_steps;
-                const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
+                F4 na, nb;
+                if constexpr (FEAT & F_DEEP) {          // the top levels from LDS, the rest from global memory
+                    if (node < P.n_tbvh_hot) { na = ld4(B0, node * BVH_WORDS); nb = ld4(B0, node * BVH_WORDS + 4); }
+                    else { const float *BG = S.G + P.off_tbvh; na = ld4(BG, node * BVH_WORDS); nb = ld4(BG, node * BVH_WORDS + 4); }
+                } else { na = ld4(B0, node * BVH_WORDS); nb = ld4(B0, node * BVH_WORDS + 4); }
                 MRT_PROBE_TBVH_PART(node, f2u(B0[(tb + 1u) * BVH_WORDS + BVH_SKIP]));
                 MRT_COUNT(CT_TBVH_NODE);
-                const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
+                const u32 skip = f2u(nb.z);
+                u32 leaf = f2u(nb.w), child = node + 1u;
+                if constexpr (FEAT & F_DEEP) { child = leaf & ~BVH_INTERNAL; leaf = (leaf & BVH_INTERNAL) ? 0u : leaf; }
                 // t = c * inv - o * inv -+ (h * |inv| + mg * |inv|)
                 const float px = fma_fast(na.x, R.inv.x, -oinv.x), py = fma_fast(na.y, R.inv.y, -oinv.y), pz = fma_fast(na.z, R.inv.z, -oinv.z);
                 const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);
@@ -449,7 +551,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                 const bool have_a = leaf_a != 0u;
                 leaf_b |= have_a ? cand : 0u;
                 leaf_a |= have_a ? 0u : cand;
-                node = (hit && leaf == 0u) ? node + 1u : skip;
+                node = (hit && leaf == 0u) ? child : skip;
                 walking = node != BVH_END && leaf_b == 0u;
             }
             if (leaf_a == 0u) { MRT_PROBE_ROUND(probe_steps, 0u, 0u); break; }
@@ -457,7 +559,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             MRT_PROBE_ROUND(probe_steps, cnt_a + cnt_b, 0u);
             for (u32 j = 0; j < cnt_a + cnt_b; ++j) {
                 const u32 id = j < cnt_a ? first_a + j : first_b + (j - cnt_a);
-                const float *T = C + P.off_tri + (tri0 + id) * TRI_WORDS;
+                const float *T = CT + P.off_tri + (tri0 + id) * TRI_WORDS;
                 float t;
                 MRT_COUNT(CT_TBVH_TRI);
                 if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t)) continue;
@@ -496,223 +598,9 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
     return mesh_isect_ref<ANY, FEAT>(S, mesh, ro, rd, m, pos, t0, i0, t1, i1);
 }
 
-// ---- wave-cooperative triangle-BVH walk -------------------------------------------------------------------------------
-// The per-lane walk above costs a wavefront the LONGEST walk of its 64 rays (mean 15 nodes, maximum 46 on the 967-triangle
-// bench mesh), and lanes whose ray misses the mesh or whose path asks no shadow query idle through it: lane utilisation 0.20.
-// Here the walk of a ray is a RANGE [node, end) of the threaded node array -- the subtree order is the array order, so any
-// index split [node, mid) + [mid, end) covers the same nodes; a walk entered at `mid` only skips box tests of ancestors in
-// front of it, i.e. it can visit more nodes than the single walk, never fewer -- and ranges move between lanes:
-//   * every lane of the wavefront that reaches the mesh instance enters, walkers with [root, end of the mesh's nodes), the
-//     others (ray missed the octree root, no query of their own) as idle helpers;
-//   * a round = at most kCoopRound box steps (until the lane holds two leaves), then the exact triangle / membership tests of
-//     those leaves, as in the per-lane walk; a lane whose range is exhausted hands the range's result to the ray's owner
-//     and turns idle;
-//   * then idle lanes take the upper half of the largest remaining ranges (span >= kCoopSplit nodes): the donor's ray -- 21
-//     floats -- and the range travel by ds_bpermute, the lane pairs are matched through 64 words of LDS.
-// Results meet in LDS: per owner one u64 minimum of (total_cmp key, first slot) and one u64 maximum of (key, last slot),
-// merged with ds_min_u64 / ds_max_u64 -- the reference's first-minimum / last-maximum rule (src/rt.rs:764-765) is the
-// lexicographic order of those pairs, so the order in which pieces finish cannot matter; t is recovered from the key, the
-// triangle from the slot (the octree leaf list entry).  Culling stays conservative and the exact tests are the same code,
-// so the answer is bit for bit the per-lane walk's (tests/test_gpu_parity.py: every mesh scene, both builds).
-constexpr u32 kCoopRoundDefault = 12u;   // box steps per round before idle lanes get a chance to take work
-constexpr u32 kCoopSplitDefault = 16u;   // smallest index span worth giving away (a subtree of ~8 leaves)
-constexpr u32 kCoopNone = 0xffffffffu;
-
-struct Walk {                // a ray in the mesh instance's frame, in the form the walk consumes
-    V3 inv, ainv, oinv, qm;  // culling: clamped reciprocal direction, |inv|, (ro - pos) * inv, margin * |inv|
-    V3 ro, rd, m;            // exact tests: the ray and Box::intersect's patched reciprocal direction
-};
-
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-typedef __attribute__((address_space(3))) u32 lds_u32;
-MRT_HD u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-MRT_HD u32 rank_in(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u)); }
-MRT_HD u32 shfl_u(u32 v, u32 src) { return (u32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
-MRT_HD float shfl_f(float v, u32 src) { return u2f(shfl_u(f2u(v), src)); }
-MRT_HD V3 shfl_v(V3 v, u32 src) { return v3(shfl_f(v.x, src), shfl_f(v.y, src), shfl_f(v.z, src)); }
-// LDS traffic between lanes of ONE wavefront: DS operations of a wave execute in issue order, so waiting for them and
-// keeping the compiler from moving memory operations across this point is all the synchronisation there is
-MRT_HD void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-
-template <bool ANY, u32 FEAT>
-__device__ inline bool tbvh_coop(const Scn &S, const float *M, V3 pos, bool walker, const Walk &mine, float &t0, i32 &i0, float &t1, i32 &i1)
-{
-    const float *F = S.F;
-    const float *C = (FEAT & F_COLD) ? S.G : S.F;
-    const Params &P = *S.P;
-    const u32 tri0 = ldu(M, MESH_TRI0), root = ldu(M, MESH_ROOT), leaf0 = ldu(M, MESH_LEAF0), tb = ldu(M, MESH_TBVH), tb_end = ldu(M, MESH_TBVH_END);
-    const float *N0 = F + P.off_node, *B0 = F + P.off_tbvh;
-    lds_u64 *MN = (lds_u64 *)S.coop, *MX = MN + 64;
-    lds_u32 *SC = (lds_u32 *)(MX + 64);
-    const u32 lane = lane_id();
-    constexpr unsigned long long kEmpty = ~0ull;
-    const u32 kCoopRound = P.coop_round, kCoopSplit = P.coop_split;
-    MN[lane] = kEmpty; MX[lane] = 0ull;                        // the slots of the ray this lane owns
-    Walk W = mine;
-    u32 owner = walker ? lane : kCoopNone, node = walker ? tb : 0u, end = walker ? tb_end : 0u;
-    unsigned long long pmin = kEmpty, pmax = 0ull;             // result of the range in hand
-    wave_sync();
-    for (u32 guard = 0; guard < 8192u; ++guard) {              // (the bound is never reached: every round shortens every range)
-        // ---- box steps, as in the per-lane walk, bounded per round
-        u32 leaf_a = 0u, leaf_b = 0u, steps = 0u;
-        bool walking = node < end;
-        while (walking) {
-            const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
-            const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
-            const float px = fma_fast(na.x, W.inv.x, -W.oinv.x), py = fma_fast(na.y, W.inv.y, -W.oinv.y), pz = fma_fast(na.z, W.inv.z, -W.oinv.z);
-            const float qx = fma_fast(na.w, W.ainv.x, W.qm.x), qy = fma_fast(nb.x, W.ainv.y, W.qm.y), qz = fma_fast(nb.y, W.ainv.z, W.qm.z);
-            const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
-            const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
-            const bool hit = !(tn > tf || tf < 0.0f);
-            const u32 cand = hit ? leaf : 0u;
-            const bool have_a = leaf_a != 0u;
-            leaf_b |= have_a ? cand : 0u;
-            leaf_a |= have_a ? 0u : cand;
-            node = (hit && leaf == 0u) ? node + 1u : skip;     // skip of a last node is BVH_END (>= end)
-            ++steps;
-            walking = node < end && leaf_b == 0u && steps < kCoopRound;
-        }
-        // ---- exact tests of the leaves in hand: Triangle::intersect + candidacy in the reference's octree walk
-        if (leaf_a != 0u) {
-            const u32 cnt_a = leaf_a >> 24, first_a = leaf_a & 0xffffffu, cnt_b = leaf_b >> 24, first_b = leaf_b & 0xffffffu;
-            for (u32 j = 0; j < cnt_a + cnt_b; ++j) {
-                const u32 id = j < cnt_a ? first_a + j : first_b + (j - cnt_a);
-                const float *T = C + P.off_tri + (tri0 + id) * TRI_WORDS;
-                float t;
-                if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), W.ro, W.rd, t)) continue;
-                const u32 head = ldu(C, P.off_memb + tri0 + id);
-                const u32 e0 = head & 0xffffffu, ne = head >> 24;
-                u32 sl = 0xffffffffu, sh = 0u;
-                bool cand = false;
-                for (u32 e = 0; e < ne; ++e) {
-                    const u32 w = ldu(C, P.off_membe + e0 + e);
-                    u32 n = root + (w >> MEMB_SLOT_BITS);
-                    bool reached = true;
-                    float a0, a1;
-                    while (n != root) {
-                        if (!box_isect(ld3(N0, n * NODE_WORDS + NODE_HALF), W.ro, W.m, add(pos, ld3(N0, n * NODE_WORDS + NODE_REL)), a0, a1)) { reached = false; break; }
-                        n = ldu(F, P.off_parent + n);
-                    }
-                    if (!reached) continue;
-                    const u32 slot = w & MEMB_SLOT_MASK;
-                    if (!cand) sl = slot;
-                    sh = slot;
-                    cand = true;
-                    if (ANY) break;
-                }
-                if (!cand) continue;
-                const unsigned long long hi = (unsigned long long)((u32)total_key(t) ^ 0x80000000u) << 32;
-                const unsigned long long lo_pair = hi | sl, hi_pair = hi | sh;
-                pmin = lo_pair < pmin ? lo_pair : pmin;         // min_by: first minimum, src/rt.rs:764
-                pmax = hi_pair > pmax ? hi_pair : pmax;         // max_by: last maximum, src/rt.rs:765
-                if (ANY) { node = end; break; }                 // Some: this ray needs nothing more
-            }
-        }
-        // ---- a range that is exhausted hands its result to the owner of the ray
-        if (owner != kCoopNone && node >= end) {
-            if (pmin != kEmpty) {
-                __hip_atomic_fetch_min(MN + owner, pmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (!ANY) __hip_atomic_fetch_max(MX + owner, pmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            owner = kCoopNone; pmin = kEmpty; pmax = 0ull;
-        }
-        wave_sync();
-        if (ANY) {                                             // pieces of a ray that has its answer are dropped
-            if (owner != kCoopNone && MN[owner] != kEmpty) { owner = kCoopNone; node = end; pmin = kEmpty; }
-        }
-        if (__builtin_amdgcn_ballot_w64(owner != kCoopNone) == 0ull) break;
-        // ---- idle lanes take the upper half of the longest remaining ranges.  The cut is a subtree boundary: the first node of
-        // the donor's skip chain -- the subtrees still to come behind the one it stands in, node -> skip(node) -> ... -- at or
-        // past the middle of its range.  Every ancestor of that entry point is an ancestor of `node`, i.e. a box the donor's
-        // ray hit, so the thief walks nothing the single walk would not have walked; and because the pending subtrees grow
-        // towards the root, the two halves are within a factor of two of each other (cutting at skip(node) alone would hand
-        // nearly the whole remaining walk from lane to lane without shortening it).
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(owner == kCoopNone);
-        if (idle != 0ull) {
-            u32 cut = end;                                     // first node the lane would give away
-            if (owner != kCoopNone && end - node >= 2u * kCoopSplit) {
-                const u32 mid = node + ((end - node) >> 1);
-                cut = ldu(B0, node * BVH_WORDS + BVH_SKIP);
-                while (cut < mid) cut = ldu(B0, cut * BVH_WORDS + BVH_SKIP);
-            }
-            const bool can = owner != kCoopNone && cut < end && end - cut >= kCoopSplit;
-            const unsigned long long busy = __builtin_amdgcn_ballot_w64(can);
-            if (busy != 0ull) {
-                const u32 nb_ = (u32)__builtin_popcountll(busy), ni_ = (u32)__builtin_popcountll(idle);
-                const u32 n = nb_ < ni_ ? nb_ : ni_;
-                const u32 rb = rank_in(busy), ri = rank_in(idle);
-                const bool donor = can && rb < n, thief = owner == kCoopNone && ri < n;
-                if (donor) SC[rb] = lane;
-                wave_sync();
-                const u32 src = thief ? SC[ri] : lane;
-                const u32 d_cut = shfl_u(cut, src), d_end = shfl_u(end, src), d_owner = shfl_u(owner, src);
-                Walk D;
-                D.inv = shfl_v(W.inv, src); D.ainv = shfl_v(W.ainv, src); D.oinv = shfl_v(W.oinv, src); D.qm = shfl_v(W.qm, src);
-                D.ro = shfl_v(W.ro, src); D.rd = shfl_v(W.rd, src); D.m = shfl_v(W.m, src);
-                if (donor) end = cut;                          // keeps [node, skip(node))
-                if (thief) { W = D; node = d_cut; end = d_end; owner = d_owner; }
-                wave_sync();                                   // SC is free again
-            }
-        }
-    }
-    wave_sync();
-    const unsigned long long mn = MN[lane], mx = MX[lane];
-    if (!walker || mn == kEmpty) return false;
-    if (ANY) return true;
-    auto key_to_t = [](u32 hi) { const i32 k = (i32)(hi ^ 0x80000000u); return k == (i32)0x80000000u ? qnan() : u2f((u32)k ^ (((u32)(k >> 31)) >> 1)); };
-    t0 = key_to_t((u32)(mn >> 32)); t1 = key_to_t((u32)(mx >> 32));
-    // slot -> triangle: the entry of the mesh's octree leaf lists (global memory: the lists are not staged)
-    i0 = (i32)ldu(S.G, P.off_leaf + leaf0 + ((u32)mn & MEMB_SLOT_MASK));
-    i1 = (i32)ldu(S.G, P.off_leaf + leaf0 + ((u32)mx & MEMB_SLOT_MASK));
-    return true;
-}
-
-// Mesh arm of Renderer::intersect through the cooperative walk.  Called by EVERY lane of the wavefront that scans this
-// instance; `want`: the lane has a query of its own (the others only help).  Same answers as mesh_isect.
-template <bool ANY, u32 FEAT>
-__device__ inline bool mesh_isect_coop(const Scn &S, u32 mesh, bool want, V3 ro, V3 rd, float dd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
-{
-    const float *F = S.F;
-    const Params &P = *S.P;
-    const float *M = F + P.off_mesh + mesh * MESH_WORDS;
-    const u32 root = ldu(M, MESH_ROOT), tb = ldu(M, MESH_TBVH);
-    if (tb == NO_NODE || !(fabs_(pos.x) < 1e6f && fabs_(pos.y) < 1e6f && fabs_(pos.z) < 1e6f))      // wave-uniform: no triangle BVH to share
-        return want && mesh_isect<ANY, FEAT>(S, mesh, ro, rd, dd, m, pos, t0, i0, t1, i1);
-    const V3 ol = sub(ro, pos);
-    const bool cull = want && cull_ok(ol, dd);
-    bool walker = false;
-    Walk W;
-    W.inv = W.ainv = W.oinv = W.qm = W.ro = W.m = v3(0.0f, 0.0f, 0.0f); W.rd = v3(0.0f, 1.0f, 0.0f);
-    if (cull) {
-        const float *N0 = F + P.off_node;
-        float a0, a1;
-        // a ray that misses the octree root has no candidates at all, src/rt.rs:745
-        walker = box_isect(ld3(N0, root * NODE_WORDS + NODE_HALF), ro, m, add(pos, ld3(N0, root * NODE_WORDS + NODE_REL)), a0, a1);
-        if (walker) {
-            const float *B0 = F + P.off_tbvh;
-            const CullRay R = cull_ray(ol, rd);
-            const F4 ra = ld4(B0, tb * BVH_WORDS), rb = ld4(B0, tb * BVH_WORDS + 4);
-            const V3 c = v3(ra.x, ra.y, ra.z), hh = v3(ra.w, rb.x, rb.y);
-            const float big = fmax_(fmax_(fabs_(pos.x), fabs_(pos.y)), fabs_(pos.z)) + fmax_(fmax_(fabs_(c.x) + hh.x, fabs_(c.y) + hh.y), fabs_(c.z) + hh.z)
-                              + fmax_(fmax_(fabs_(ol.x), fabs_(ol.y)), fabs_(ol.z));
-            const float mg = cull_margin(kMarginTri, sub(c, ol), hh, big);     // one culling margin per ray, from the mesh bounds
-            W.inv = R.inv; W.ainv = R.ainv; W.oinv = hadam(ol, R.inv); W.qm = muls(R.ainv, mg);
-            W.ro = ro; W.rd = rd; W.m = m;
-        }
-    }
-    bool hit = tbvh_coop<ANY, FEAT>(S, M, pos, walker, W, t0, i0, t1, i1);
-    // rays the triangle BVH must not cull (non-finite, non-unit) take the reference's own walk, as in mesh_isect
-    if (want && !cull) hit = mesh_isect_ref<ANY, FEAT>(S, mesh, ro, rd, m, pos, t0, i0, t1, i1);
-    return hit;
-}
-#endif
-
 // Renderer::intersect for flat instance i (record words ia, ib): the exact test of the reference, src/rt.rs:725-774
-// COOP (device, mesh kernels without an instance BVH): every lane of the wavefront calls this for the same instance i;
-// `want` = the lane has a query (lanes without one only help in the cooperative mesh walk).
-template <bool ANY, u32 FEAT, bool COOP = false>
-MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia, const F4 &ib, float &t0, float &t1, i32 &i0, i32 &i1, bool want = true)
+template <bool ANY, u32 FEAT>
+MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia, const F4 &ib, float &t0, float &t1, i32 &i0, i32 &i1)
 {
     const float *F = S.U;
     const Params &P = *S.P;
@@ -732,15 +620,6 @@ MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia,
         dd = dot(rd, rd);
     }
     t0 = 0.0f; t1 = 0.0f; i0 = -1; i1 = -1;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (COOP) {
-        if (kind == KIND_MESH) {              // wave-uniform
-            const float *R = F + P.off_rend + ldu(F, P.off_instx + i * INSTX_WORDS + INSTX_REND) * REND_WORDS;
-            return mesh_isect_coop<ANY, FEAT>(S, ldu(R, REND_GEO), want, ro, rd, dd, m, pos, t0, i0, t1, i1);
-        }
-        if (!want) return false;
-    }
-#endif
     if (kind == KIND_SPHERE) return sphere_isect(ia.w, sub(ro, pos), rd, dd, t0, t1);
     if (kind == KIND_PLANE) { const bool h = plane_isect(v3(ib.y, ib.z, ib.w), ia.w, ro, rd, t0); t1 = t0; return h; }
     if ((FEAT & F_BOX) && kind == KIND_BOX) return box_isect(v3(ia.w, ib.y, ib.z), ro, m, pos, t0, t1);
@@ -763,47 +642,13 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 // BVH variant, visiting candidates in tree order, returns the very same hit.  ANY = true answers only Some / None
 // (the shadow query of src/rt.rs:1036).  The linear loop fetches each record one iteration ahead of its use.
 template <bool ANY, u32 FEAT>
-MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best, bool want = true)
+MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
 {
     const float *F = S.U;
     const Params &P = *S.P;
     i32 best_key = 0x7fffffff;
     best.rend = -1; best.inst = 0; best.t0 = 0.0f; best.t1 = 0.0f; best.i0 = -1; best.i1 = -1;
     const float *I = F + P.off_inst;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (coop_for(FEAT)) {
-        // Every lane of the wavefront is here (`want`: with a query of its own) and scans the instances in lock-step, so
-        // that a mesh instance is met by all 64 lanes at once and its triangle-BVH walk can be shared (tbvh_coop).  ANY: a
-        // lane that has its answer stays in the loop as a helper until every lane is served.
-        const u32 n = P.n_inst;
-        bool found = false;
-        if (n) {
-            F4 qa = ld4(I, 0), qb = ld4(I, 4);
-            for (u32 j = 0; j < n; ++j) {
-                const F4 ia = qa, ib = qb;
-                if (j + 1 < n) { qa = ld4(I, (j + 1) * INST_WORDS); qb = ld4(I, (j + 1) * INST_WORDS + 4); }
-                float t0, t1;
-                i32 i0, i1;
-                const bool asks = want && !found;
-                if (isect_instance<ANY, FEAT, true>(S, ray, j, ia, ib, t0, t1, i0, i1, asks)) {
-                    if (ANY) found = true;
-                    else {
-                        const i32 key = total_key(t0);
-                        if (key < best_key) {       // in order: a strict compare keeps the first minimum (see below)
-                            best_key = key;
-                            best.rend = 0; best.inst = j; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
-                        }
-                    }
-                }
-                if (ANY && wave_all(found || !want)) break;
-            }
-        }
-        if (ANY) return found;
-        if (best.rend < 0) return false;
-        best.rend = (i32)ldu(S.F, P.off_instx + best.inst * INSTX_WORDS + INSTX_REND);
-        return true;
-    }
-#endif
 
     if (ANY) { MRT_COUNT(CT_TRACE_ANY); } else { MRT_COUNT(CT_TRACE); }
     // IN_ORDER: candidates arrive in increasing flat index (the linear scan of a scene without an instance BVH), so the
@@ -947,7 +792,7 @@ MRT_HD V3 hit_normal(const Scn &S, const Obj &o, V3 n_hit, i32 tri_idx)
     else if ((FEAT & F_TRI) && o.kind == KIND_TRIANGLE) n = cross(ld3(o.R, REND_GEO + 3), ld3(o.R, REND_GEO + 6));
     else if (FEAT & F_TRI) {
         const float *M = S.F + S.P->off_mesh + ldu(o.R, REND_GEO) * MESH_WORDS;
-        const float *T = ((FEAT & F_COLD) ? S.G : S.F) + S.P->off_tri + (ldu(M, MESH_TRI0) + (u32)tri_idx) * TRI_WORDS;
+        const float *T = ((FEAT & F_DEEP) ? S.G : S.F) + S.P->off_tri + (ldu(M, MESH_TRI0) + (u32)tri_idx) * TRI_WORDS;
         n = cross(ld3(T, 3), ld3(T, 6));
     }
     return norm(xf_vec(o.X, o.ident, n));
@@ -1093,7 +938,6 @@ struct RegStash {
     MRT_HD float get(u32 slot) const { return v[slot]; }
 };
 #if defined(__HIPCC__) || defined(__HIP__)
-typedef __attribute__((address_space(3))) volatile float lds_vfloat;   // keeps ds_read / ds_write addressing
 template <u32 THREADS>
 struct LdsStash {
     lds_vfloat *base;         // &lds_stash[tid]; slot-major columns of THREADS floats
@@ -1171,123 +1015,96 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
         bool ended = false;
         V3 X = v3(0.0f, 1.0f, 0.0f);             // un-normalised direction of the next ray
         V3 base = o;                             // the point it leaves from (hit point, or lens position)
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (coop_for(FEAT)) {
-            bool cont = false;                       // the path goes on behind this hit
-            V3 s_p0 = v3(0, 0, 0), s_hp = v3(0, 0, 0), s_hn = v3(0, 0, 1), s_color = v3(0, 0, 0);
-            float s_rough = 0.0f, s_metal = 0.0f;
-            if (!trace<false, FEAT>(S, ray, h)) {
-                // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
-                contrib = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
+        if (!trace<false, FEAT>(S, ray, h)) {
+            // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
+            contrib = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
+            ended = true;
+        } else {
+            MRT_PROBE(PH_SHADE);
+            const Obj ob = obj_of(S, h);
+            const V3 p0 = add(o, muls(d, h.t0));                       // Vec3f::from(&hit.0.ray)
+            const V3 nh0 = to_object(ob, p0);
+            const Surf sf0 = surf_of<FEAT>(S, h, ob, nh0);
+            const float opacity0 = surf_scalar<FEAT>(S, sf0, MAP_OPACITY, MAT_OPACITY);
+            const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
+
+            // Scatter.  The reference always builds the reflected ray at hit0 (src/rt.rs:1049) and replaces it by the
+            // refracted ray from the exit hit when the 15 % / opacity coin comes up and refraction is possible
+            // (src/rt.rs:1054-1058).  Draws are slot-addressed, so only the ray that survives is computed: lanes that
+            // try to refract and lanes that reflect share one pass through the normal / perturbation code; a failed
+            // refraction (total internal reflection) takes a second pass as a reflection.
+            bool refr = coin(fmin_(1.0f - opacity0, 0.85f), pk, dim_of(b, SL_OPAC_COIN));
+            V3 hp, hn;
+            Surf sfh;
+            u32 pass = 0;
+            for (;;) {
+                if (pass == 0) { MRT_PROBE(PH_SCATTER1); } else { MRT_PROBE(PH_SCATTER2); }
+                ++pass;
+                if (refr) { MRT_PROBE(PH_REFRACT); }
+                if (ob.kind != KIND_PLANE) { MRT_PROBE(PH_NORMAL_NONPLANE); }
+                hp = refr ? add(o, muls(d, h.t1)) : p0;                 // recorded hit point: hit.1 or hit.0
+                const V3 nhh = refr ? to_object(ob, hp) : nh0;
+                hn = hit_normal<FEAT>(S, ob, nhh, refr ? h.i1 : h.i0);
+                sfh = sf0;
+                if (refr) sfh = surf_of<FEAT>(S, h, ob, nhh);
+                float rough = surf_scalar<FEAT>(S, sfh, MAP_ROUGH, MAT_ROUGH);            // Ray::reflect / Ray::refract, src/rt.rs:559-589
+                const float opac = refr ? surf_scalar<FEAT>(S, sfh, MAP_OPACITY, MAT_OPACITY) : opacity0;
+                const u32 dbase = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);    // coin, u1, u2 are consecutive slots
+                if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, dbase) < kThr080) rough = 1.0f;
+                const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, dbase + 1u)), u32_to_unit(draw_u32(pk, dbase + 2u)));
+                if (refr) {
+                    const float eta = 1.0f + 0.5f * surf_scalar<FEAT>(S, sfh, MAP_GLASS, MAT_GLASS);
+                    if (refract(d, eta, nn, X)) break;                  // .norm() of src/rt.rs:586 happens at the bottom
+                    refr = false;                                       // Vec3f::refract returned None
+                    continue;
+                }
+                X = reflect(d, nn);                                     // .norm() of src/rt.rs:569 happens at the bottom
+                break;
+            }
+            base = hp;
+
+            // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
+            const V3 color = surf_color<FEAT>(S, sfh);
+            const float emit = surf_scalar<FEAT>(S, sfh, MAP_EMIT, MAT_EMIT);
+            if (coin(emit, pk, dim_of(b, SL_EMIT_COIN))) {
+                MRT_PROBE(PH_EMIT_END);
+                contrib = add(L, hadam(T, color));
                 ended = true;
             } else {
-                MRT_PROBE(PH_SHADE);
-                const Obj ob = obj_of(S, h);
-                const V3 p0 = add(o, muls(d, h.t0));                       // Vec3f::from(&hit.0.ray)
-                const V3 nh0 = to_object(ob, p0);
-                const Surf sf0 = surf_of<FEAT>(S, h, ob, nh0);
-                const float opacity0 = surf_scalar<FEAT>(S, sf0, MAP_OPACITY, MAT_OPACITY);
-                const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
-
-                // Scatter.  The reference always builds the reflected ray at hit0 (src/rt.rs:1049) and replaces it by the
-                // refracted ray from the exit hit when the 15 % / opacity coin comes up and refraction is possible
-                // (src/rt.rs:1054-1058).  Draws are slot-addressed, so only the ray that survives is computed: lanes that
-                // try to refract and lanes that reflect share one pass through the normal / perturbation code; a failed
-                // refraction (total internal reflection) takes a second pass as a reflection.
-                bool refr = coin(fmin_(1.0f - opacity0, 0.85f), pk, dim_of(b, SL_OPAC_COIN));
-                V3 hp, hn;
-                Surf sfh;
-                u32 pass = 0;
-                for (;;) {
-                    if (pass == 0) { MRT_PROBE(PH_SCATTER1); } else { MRT_PROBE(PH_SCATTER2); }
-                    ++pass;
-                    if (refr) { MRT_PROBE(PH_REFRACT); }
-                    if (ob.kind != KIND_PLANE) { MRT_PROBE(PH_NORMAL_NONPLANE); }
-                    hp = refr ? add(o, muls(d, h.t1)) : p0;                 // recorded hit point: hit.1 or hit.0
-                    const V3 nhh = refr ? to_object(ob, hp) : nh0;
-                    hn = hit_normal<FEAT>(S, ob, nhh, refr ? h.i1 : h.i0);
-                    sfh = sf0;
-                    if (refr) sfh = surf_of<FEAT>(S, h, ob, nhh);
-                    float rough = surf_scalar<FEAT>(S, sfh, MAP_ROUGH, MAT_ROUGH);            // Ray::reflect / Ray::refract, src/rt.rs:559-589
-                    const float opac = refr ? surf_scalar<FEAT>(S, sfh, MAP_OPACITY, MAT_OPACITY) : opacity0;
-                    const u32 dbase = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);    // coin, u1, u2 are consecutive slots
-                    if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, dbase) < kThr080) rough = 1.0f;
-                    const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, dbase + 1u)), u32_to_unit(draw_u32(pk, dbase + 2u)));
-                    if (refr) {
-                        const float eta = 1.0f + 0.5f * surf_scalar<FEAT>(S, sfh, MAP_GLASS, MAT_GLASS);
-                        if (refract(d, eta, nn, X)) break;                  // .norm() of src/rt.rs:586 happens at the bottom
-                        refr = false;                                       // Vec3f::refract returned None
-                        continue;
-                    }
-                    X = reflect(d, nn);                                     // .norm() of src/rt.rs:569 happens at the bottom
-                    break;
-                }
-                base = hp;
-
-                // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
-                const V3 color = surf_color<FEAT>(S, sfh);
-                const float emit = surf_scalar<FEAT>(S, sfh, MAP_EMIT, MAT_EMIT);
-                if (coin(emit, pk, dim_of(b, SL_EMIT_COIN))) {
-                    MRT_PROBE(PH_EMIT_END);
-                    contrib = add(L, hadam(T, color));
-                    ended = true;
-                } else {
-                    // direct light: the shadow queries are asked below, where the wavefront has reconverged
-                    cont = true;
-                    s_p0 = p0; s_hp = hp; s_hn = hn; s_color = color;
-                    if ((FEAT & F_LIGHTS) && P.n_light) {
-                        s_rough = surf_scalar<FEAT>(S, sfh, MAP_ROUGH, MAT_ROUGH);
-                        s_metal = surf_scalar<FEAT>(S, sfh, MAP_METAL, MAT_METAL);
-                    }
-                }
-            }
-            if constexpr (FEAT & F_LIGHTS) {
-                // direct light, visibility from hit0 (src/rt.rs:1027-1046), shading at the recorded hit (:973-987).  Every lane of the
-                // wavefront asks (or only helps with) the shadow query of each light at the same point: lanes whose path ended, whose
-                // light term is zero or who missed everything take part in the cooperative mesh walks of the others.
-                if (P.n_light) {
+                // direct light, visibility from hit0 (src/rt.rs:1027-1046), shading at the recorded hit (:973-987)
+                if ((FEAT & F_LIGHTS) && P.n_light) {
                     V3 l_col = v3(0.0f, 0.0f, 0.0f);
+                    const float rough_h = surf_scalar<FEAT>(S, sfh, MAP_ROUGH, MAT_ROUGH);
+                    const float metal_h = surf_scalar<FEAT>(S, sfh, MAP_METAL, MAT_METAL);
                     for (u32 li = 0; li < P.n_light; ++li) {
-                        V3 term = v3(0.0f, 0.0f, 0.0f), so = v3(0.0f, 0.0f, 0.0f), ls = v3(0.0f, 1.0f, 0.0f);
-                        bool ask = false;
-                        if (cont) {
-                            const V3 hp = s_hp, hn = s_hn, color = s_color, p0 = s_p0;
-                            const float rough_h = s_rough, metal_h = s_metal;
-                            {
-                            const float *Lt = S.F + P.off_light + li * LIGHT_WORDS;
-                            const bool point = ldu(Lt, LIGHT_KIND) == LK_POINT;
-                            const V3 lv = ld3(Lt, LIGHT_V);
-                            // The light's term of the fold (src/rt.rs:973-987), evaluated before its shadow ray: when it is exactly zero
-                            // (surface facing away and no highlight: diff == 0, spec == 0) the light's visibility cannot change l_col
-                            // -- l_col is never -0, so adding +-0 leaves every bit -- and the shadow ray (src/rt.rs:1027-1045, a
-                            // whole any-hit traversal) is not traced.  A NaN anywhere in the term compares unequal to zero and takes
-                            // the reference's route.
-                            const V3 ln = point ? norm(sub(lv, hp)) : lv;             // l.norm() at the recorded hit
-                            const float diff = fmax_(dot(ln, hn), 0.0f);
-                            const float sp = fmax_(dot(d, reflect(ln, hn)), 0.0f);
-                            const float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16;   // powi(32)
-                            const float spec = s32 * (1.0f - rough_h);
-                            const V3 o_col = muls(color, 1.0f - metal_h);
-                            V3 t = hadam(muls(o_col, diff), ld3(Lt, LIGHT_COLOR));
-                            t = v3(t.x + spec, t.y + spec, t.z + spec);
-                            term = muls(t, Lt[LIGHT_PWR]);
-                            ask = !(term.x == 0.0f && term.y == 0.0f && term.z == 0.0f);
-                            if (ask) {
-                                ls = point ? norm(sub(lv, p0)) : lv;                  // l.norm() at hit0
-                                so = add(p0, muls(ls, kE));                           // Ray::cast_default
-                            }
-                            }
-                        }
+                        const float *Lt = S.F + P.off_light + li * LIGHT_WORDS;
+                        const bool point = ldu(Lt, LIGHT_KIND) == LK_POINT;
+                        const V3 lv = ld3(Lt, LIGHT_V);
+                        // The light's term of the fold (src/rt.rs:973-987), evaluated before its shadow ray: when it is exactly zero
+                        // (surface facing away and no highlight: diff == 0, spec == 0) the light's visibility cannot change l_col
+                        // -- l_col is never -0, so adding +-0 leaves every bit -- and the shadow ray (src/rt.rs:1027-1045, a
+                        // whole any-hit traversal) is not traced.  A NaN anywhere in the term compares unequal to zero and takes
+                        // the reference's route.
+                        const V3 ln = point ? norm(sub(lv, hp)) : lv;             // l.norm() at the recorded hit
+                        const float diff = fmax_(dot(ln, hn), 0.0f);
+                        const float sp = fmax_(dot(d, reflect(ln, hn)), 0.0f);
+                        const float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16;   // powi(32)
+                        const float spec = s32 * (1.0f - rough_h);
+                        const V3 o_col = muls(color, 1.0f - metal_h);
+                        V3 t = hadam(muls(o_col, diff), ld3(Lt, LIGHT_COLOR));
+                        t = v3(t.x + spec, t.y + spec, t.z + spec);
+                        const V3 term = muls(t, Lt[LIGHT_PWR]);
+                        if (term.x == 0.0f && term.y == 0.0f && term.z == 0.0f) continue;
+                        const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
+                        const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
                         Hit hs;
-                        const bool blocked = trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs, ask);
-                        if (ask && !blocked) l_col = add(l_col, term);
+                        if (trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs)) continue;
+                        l_col = add(l_col, term);
                     }
                     // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
-                    if (cont) L = add(L, hadam(T, muls(l_col, pwr)));
+                    L = add(L, hadam(T, muls(l_col, pwr)));
                 }
-            }
-            if (cont) {
-                T = hadam(T, muls(v3(0.5f + s_color.x, 0.5f + s_color.y, 0.5f + s_color.z), pwr));
+                T = hadam(T, muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr));
                 pwr = pwr * P.q;                                        // Ray::cast, src/rt.rs:571
                 ++b;
                 if (b > P.bounce) {          // src/rt.rs:1018
@@ -1295,108 +1112,8 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                     ended = true;
                 }
             }
-        } else
-#endif
-        {
-            if (!trace<false, FEAT>(S, ray, h)) {
-                // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
-                contrib = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
-                ended = true;
-            } else {
-                MRT_PROBE(PH_SHADE);
-                const Obj ob = obj_of(S, h);
-                const V3 p0 = add(o, muls(d, h.t0));                       // Vec3f::from(&hit.0.ray)
-                const V3 nh0 = to_object(ob, p0);
-                const Surf sf0 = surf_of<FEAT>(S, h, ob, nh0);
-                const float opacity0 = surf_scalar<FEAT>(S, sf0, MAP_OPACITY, MAT_OPACITY);
-                const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
-
-                // Scatter.  The reference always builds the reflected ray at hit0 (src/rt.rs:1049) and replaces it by the
-                // refracted ray from the exit hit when the 15 % / opacity coin comes up and refraction is possible
-                // (src/rt.rs:1054-1058).  Draws are slot-addressed, so only the ray that survives is computed: lanes that
-                // try to refract and lanes that reflect share one pass through the normal / perturbation code; a failed
-                // refraction (total internal reflection) takes a second pass as a reflection.
-                bool refr = coin(fmin_(1.0f - opacity0, 0.85f), pk, dim_of(b, SL_OPAC_COIN));
-                V3 hp, hn;
-                Surf sfh;
-                u32 pass = 0;
-                for (;;) {
-                    if (pass == 0) { MRT_PROBE(PH_SCATTER1); } else { MRT_PROBE(PH_SCATTER2); }
-                    ++pass;
-                    if (refr) { MRT_PROBE(PH_REFRACT); }
-                    if (ob.kind != KIND_PLANE) { MRT_PROBE(PH_NORMAL_NONPLANE); }
-                    hp = refr ? add(o, muls(d, h.t1)) : p0;                 // recorded hit point: hit.1 or hit.0
-                    const V3 nhh = refr ? to_object(ob, hp) : nh0;
-                    hn = hit_normal<FEAT>(S, ob, nhh, refr ? h.i1 : h.i0);
-                    sfh = sf0;
-                    if (refr) sfh = surf_of<FEAT>(S, h, ob, nhh);
-                    float rough = surf_scalar<FEAT>(S, sfh, MAP_ROUGH, MAT_ROUGH);            // Ray::reflect / Ray::refract, src/rt.rs:559-589
-                    const float opac = refr ? surf_scalar<FEAT>(S, sfh, MAP_OPACITY, MAT_OPACITY) : opacity0;
-                    const u32 dbase = dim_of(b, refr ? SL_REFR_COIN : SL_REFL_COIN);    // coin, u1, u2 are consecutive slots
-                    if (metal_c == 0.0f && opac != 0.0f && draw_u32(pk, dbase) < kThr080) rough = 1.0f;
-                    const V3 nn = rand_normal(hn, rough, u32_to_unit(draw_u32(pk, dbase + 1u)), u32_to_unit(draw_u32(pk, dbase + 2u)));
-                    if (refr) {
-                        const float eta = 1.0f + 0.5f * surf_scalar<FEAT>(S, sfh, MAP_GLASS, MAT_GLASS);
-                        if (refract(d, eta, nn, X)) break;                  // .norm() of src/rt.rs:586 happens at the bottom
-                        refr = false;                                       // Vec3f::refract returned None
-                        continue;
-                    }
-                    X = reflect(d, nn);                                     // .norm() of src/rt.rs:569 happens at the bottom
-                    break;
-                }
-                base = hp;
-
-                // emit coin of the fold, src/rt.rs:966-970: replaces everything behind this hit
-                const V3 color = surf_color<FEAT>(S, sfh);
-                const float emit = surf_scalar<FEAT>(S, sfh, MAP_EMIT, MAT_EMIT);
-                if (coin(emit, pk, dim_of(b, SL_EMIT_COIN))) {
-                    MRT_PROBE(PH_EMIT_END);
-                    contrib = add(L, hadam(T, color));
-                    ended = true;
-                } else {
-                    // direct light, visibility from hit0 (src/rt.rs:1027-1046), shading at the recorded hit (:973-987)
-                    if ((FEAT & F_LIGHTS) && P.n_light) {
-                        V3 l_col = v3(0.0f, 0.0f, 0.0f);
-                        const float rough_h = surf_scalar<FEAT>(S, sfh, MAP_ROUGH, MAT_ROUGH);
-                        const float metal_h = surf_scalar<FEAT>(S, sfh, MAP_METAL, MAT_METAL);
-                        for (u32 li = 0; li < P.n_light; ++li) {
-                            const float *Lt = S.F + P.off_light + li * LIGHT_WORDS;
-                            const bool point = ldu(Lt, LIGHT_KIND) == LK_POINT;
-                            const V3 lv = ld3(Lt, LIGHT_V);
-                            // The light's term of the fold (src/rt.rs:973-987), evaluated before its shadow ray: when it is exactly zero
-                            // (surface facing away and no highlight: diff == 0, spec == 0) the light's visibility cannot change l_col
-                            // -- l_col is never -0, so adding +-0 leaves every bit -- and the shadow ray (src/rt.rs:1027-1045, a
-                            // whole any-hit traversal) is not traced.  A NaN anywhere in the term compares unequal to zero and takes
-                            // the reference's route.
-                            const V3 ln = point ? norm(sub(lv, hp)) : lv;             // l.norm() at the recorded hit
-                            const float diff = fmax_(dot(ln, hn), 0.0f);
-                            const float sp = fmax_(dot(d, reflect(ln, hn)), 0.0f);
-                            const float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16;   // powi(32)
-                            const float spec = s32 * (1.0f - rough_h);
-                            const V3 o_col = muls(color, 1.0f - metal_h);
-                            V3 t = hadam(muls(o_col, diff), ld3(Lt, LIGHT_COLOR));
-                            t = v3(t.x + spec, t.y + spec, t.z + spec);
-                            const V3 term = muls(t, Lt[LIGHT_PWR]);
-                            if (term.x == 0.0f && term.y == 0.0f && term.z == 0.0f) continue;
-                            const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
-                            const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
-                            Hit hs;
-                            if (trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs)) continue;
-                            l_col = add(l_col, term);
-                        }
-                        // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
-                        L = add(L, hadam(T, muls(l_col, pwr)));
-                    }
-                    T = hadam(T, muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr));
-                    pwr = pwr * P.q;                                        // Ray::cast, src/rt.rs:571
-                    ++b;
-                    if (b > P.bounce) {          // src/rt.rs:1018
-                        contrib = add(L, hadam(T, sky_init));
-                        ended = true;
-                    }
-                }
-            }
         }
+    
         bool from_camera = false;
         if (ended) {
             csum = add(csum, contrib);

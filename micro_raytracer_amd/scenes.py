@@ -124,11 +124,21 @@ def bumpy_mesh(n_target=967, seed=7):
     return tris[:n_target].astype(np.float32)
 
 
+def big_mesh(n_tris):
+    """A closed icosphere-based mesh of the first n_tris triangles of the smallest subdivision that has them (5120 -> 4,
+    20480 -> 5): the shape of the reference's Mesh.json scene with a mesh the LDS cannot hold."""
+    sub = 0
+    while 20 * 4 ** sub < n_tris:
+        sub += 1
+    return icosphere(sub, 0.45, (1.3, 1.0, 1.1))[:n_tris]
+
+
 def mesh_scene(res=(1920, 1080), ssaa=1, sample=256, bounce=8, n_tris=967, inline=False):
-    """example/Mesh.json shape: ~1k-triangle mesh (octree depth 3) + textured plane + point light (configs[4])."""
+    """example/Mesh.json shape: ~1k-triangle mesh (octree depth 3) + textured plane + point light (configs[4]).
+    n_tris > 1280: the same scene around big_mesh(n_tris) (any mesh size is legal input, src/parser.rs:805-824)."""
     from .scene import mesh_to_inline
-    tris = bumpy_mesh(n_tris)
-    mesh = mesh_to_inline(tris) if inline else [[[float(c) for c in vv] for vv in t] for t in tris]
+    tris = bumpy_mesh(n_tris) if n_tris <= 1280 else big_mesh(n_tris)
+    mesh = mesh_to_inline(tris) if inline else (np.asarray(tris, np.float32) if n_tris > 1280 else [[[float(c) for c in vv] for vv in t] for t in tris])
     return {
         "rt": {"sample": sample, "bounce": bounce},
         "frame": _frame(res, ssaa, {"aprt": 0.008, "foc": 0.725, "fov": 60}),

@@ -57,13 +57,21 @@ int emu_features(const mrt_render_desc *d)
 }
 
 // the megakernel's per-lane body over every pixel of rows [row0,row1) (frame rows), accumulating into accum[nh][nw][3]
-int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, uint32_t n_samples, uint32_t row0, uint32_t row1,
-               uint32_t threads, float *accum, uint64_t *segments)
+// deep_nodes > 0: the F_COLD | F_DEEP form of the lane code on a level-ordered triangle-BVH table of which the first deep_nodes
+// nodes count as staged (on the CPU both halves are the same memory: this checks the ordering, the child links and the walk)
+int emu_render_deep(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, uint32_t n_samples, uint32_t row0, uint32_t row1,
+                    uint32_t threads, float *accum, uint64_t *segments, uint32_t deep_nodes)
 {
     Packed pk;
-    const int rc = pack_scene(d, pk, g_err);
+    PackOpts po;
+    const bool warm_only = deep_nodes == 0xffffffffu;      // F_COLD without F_DEEP: the queued closest-hit walk on the depth-first table
+    if (warm_only) deep_nodes = 0;
+    po.tbvh_level_order = deep_nodes != 0;
+    const int rc = pack_scene(d, pk, g_err, po);
     if (rc) return rc;
+    if (deep_nodes && !pk.tbvh_level_order) { g_err = "no triangle BVH to order"; return -100; }
     Params P = pk.P;
+    P.n_tbvh_hot = deep_nodes;
     P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
     P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32);
     P.n_samples = n_samples; P.sample_base = sample_base; P.k_split = 1; P.accum = accum;
@@ -83,7 +91,12 @@ int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, ui
             if (y >= row1) break;
             for (uint32_t x = 0; x < pk.nw; ++x) {
                 u32 sg = 0;
-                { RegStash st; LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u; if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg); }
+                {
+                    RegStash st; LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u;
+                    if (warm_only) { if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH | F_COLD>(S, st, x, y, job, sg); else render_pixel<F_ALL | F_COLD>(S, st, x, y, job, sg); }
+                    else if (deep_nodes) { if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH | F_COLD | F_DEEP>(S, st, x, y, job, sg); else render_pixel<F_ALL | F_COLD | F_DEEP>(S, st, x, y, job, sg); }
+                    else if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg);
+                }
                 local += sg;
             }
         }
@@ -92,6 +105,12 @@ int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, ui
     for (auto &th : pool) th.join();
     if (segments) *segments = segs.load();
     return 0;
+}
+
+int emu_render(const mrt_render_desc *d, uint64_t seed, uint32_t sample_base, uint32_t n_samples, uint32_t row0, uint32_t row1,
+               uint32_t threads, float *accum, uint64_t *segments)
+{
+    return emu_render_deep(d, seed, sample_base, n_samples, row0, row1, threads, accum, segments, 0);
 }
 
 // Sampler::img through the kernels' per-element bodies

@@ -58,7 +58,7 @@ def layout(holder):
     return dict(zip(LAYOUT_KEYS, list(out)))
 
 
-def render(holder, seed, n_samples, sample_base=0, rows=None, threads=8, accum=None):
+def render(holder, seed, n_samples, sample_base=0, rows=None, threads=8, accum=None, deep_nodes=0):
     L = lib()
     info = pack(holder)
     nw, nh = info["nw"], info["nh"]
@@ -66,7 +66,7 @@ def render(holder, seed, n_samples, sample_base=0, rows=None, threads=8, accum=N
         accum = np.zeros((nh, nw, 3), np.float32)
     seg = C.c_uint64()
     r0, r1 = rows if rows else (0, nh)
-    rc = L.emu_render(C.cast(holder.ptr(), C.c_void_p), seed, sample_base, n_samples, r0, r1, threads, _fp(accum), C.byref(seg))
+    rc = L.emu_render_deep(C.cast(holder.ptr(), C.c_void_p), C.c_uint64(seed), sample_base, n_samples, r0, r1, threads, _fp(accum), C.byref(seg), deep_nodes)
     if rc:
         raise ValueError((rc, L.emu_error().decode()))
     return accum, seg.value

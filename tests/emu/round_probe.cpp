@@ -26,7 +26,7 @@ extern "C" int probe_rounds(const mrt_render_desc *d, uint64_t seed, uint32_t n_
     P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
     P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.k_split = 1; P.sample_base = 0; P.n_samples = n_samples;
     std::vector<float> frame((size_t)pk.nw * pk.nh * 3, 0.0f); P.accum = frame.data();
-    Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.G = S.F; S.P = &P; S.coop = nullptr;
+    Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.G = S.F; S.P = &P;
     std::vector<std::vector<std::vector<Call>>> rec(64);
     size_t mx = 0;
     for (int l = 0; l < 64; ++l) {
@@ -36,7 +36,7 @@ extern "C" int probe_rounds(const mrt_render_desc *d, uint64_t seed, uint32_t n_
         g_iters = nullptr;
         if (rec[l].size() > mx) mx = rec[l].size();
     }
-    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
     for (size_t k = 0; k < mx; ++k) {
         out[0] += 1;
         // calls line up by index within the iteration only if every lane makes the same calls; lanes skip calls (no shadow
@@ -48,6 +48,16 @@ extern "C" int probe_rounds(const mrt_render_desc *d, uint64_t seed, uint32_t n_
             size_t nr = 0; bool anyc = false;
             for (int l = 0; l < 64; ++l) if (k < rec[l].size() && c < rec[l][k].size()) { anyc = true; if (rec[l][k][c].rounds.size() > nr) nr = rec[l][k][c].rounds.size(); out[7] += 1.0 / 64; }
             if (anyc) out[6] += 1;
+            {   // the same call with every leaf postponed: one box phase (max over lanes of the lane's total steps), one exact phase
+                unsigned ts = 0, tt = 0;
+                for (int l = 0; l < 64; ++l) if (k < rec[l].size() && c < rec[l][k].size()) {
+                    unsigned a = 0, b = 0;
+                    for (const Rd &q : rec[l][k][c].rounds) { a += q.steps; b += q.tris; }
+                    if (a > ts) ts = a;
+                    if (b > tt) tt = b;
+                }
+                out[8 + 2 * c] += ts; out[9 + 2 * c] += tt;
+            }
             for (size_t r = 0; r < nr; ++r) {
                 unsigned ms = 0, mt = 0;
                 for (int l = 0; l < 64; ++l) if (k < rec[l].size() && c < rec[l][k].size() && r < rec[l][k][c].rounds.size()) {
@@ -57,6 +67,7 @@ extern "C" int probe_rounds(const mrt_render_desc *d, uint64_t seed, uint32_t n_
                     out[4] += q.steps / 64.0; out[5] += q.tris / 64.0;
                 }
                 out[1] += ms; out[2] += mt; out[3] += 1;
+                out[12 + 2 * c] += ms; out[13 + 2 * c] += mt;
             }
         }
     }

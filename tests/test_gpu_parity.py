@@ -203,6 +203,43 @@ def test_every_launch_shape_gives_the_same_bits(monkeypatch):
         assert len(seen) >= 3          # the shapes really differed (big scenes refuse the small workgroups)
 
 
+def test_every_staging_level_gives_the_same_bits(monkeypatch):
+    """What a workgroup stages in LDS is a layout choice (csrc/mrt_api.cpp): the whole scene, the warm prefix (membership
+    tables and texels read from global memory; the mesh kernels queue every leaf of a closest-hit walk), the deep level (the
+    triangle-BVH table in level order, only its first nodes staged, triangles in global memory), nothing (all through L2).
+    Every level must give the same accumulator bits, for every workgroup size it admits."""
+    from micro_raytracer_amd import scenes
+    for desc in (scenes.kitchen_sink(res=(80, 48), sample=16), scenes.mesh_scene(res=(96, 54), sample=8, n_tris=600),
+                 scenes.minecraft_like(res=(64, 40), ssaa=1, sample=8)):
+        render, _ = make_holder(desc)
+        spp = render.rt.sample
+        has_mesh = any(o.kind == "mesh" for o in render.scene.renderer)
+        monkeypatch.setenv("MRT_COLD", "0")
+        base = _gpu_render(render, spp)
+        ref = base.accum()[0]
+        assert base.stats()["kernel_features"] & 64 == 0
+        monkeypatch.delenv("MRT_COLD")
+        seen = set()
+        levels = [{"MRT_COLD": "1"}] + ([{"MRT_DEEP_NODES": "3"}, {"MRT_DEEP_NODES": "40"}, {"MRT_DEEP_NODES": "100000"}] if has_mesh else [])
+        for env in levels:
+            for threads in (None, "256", "512", "1024"):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                if threads:
+                    monkeypatch.setenv("MRT_BLOCK_THREADS", threads)
+                s = _gpu_render(render, spp)
+                got = s.accum()[0]
+                st = s.stats()
+                seen.add((st["kernel_features"] & 192, st["block_threads"]))
+                s.close()
+                for k in list(env) + ["MRT_BLOCK_THREADS"]:
+                    monkeypatch.delenv(k, raising=False)
+                assert st["kernel_features"] & 64, (env, threads, st)
+                assert bool(st["kernel_features"] & 128) == ("MRT_DEEP_NODES" in env), (env, st)
+                assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (env, threads)
+        assert len(seen) >= (6 if has_mesh else 3), seen
+
+
 def test_shards_reassemble_to_whole_frame():
     """Row shards (block-cyclic, 8-row blocks) of 3 contexts tile the single-context frame bit for bit."""
     from micro_raytracer_amd import scenes
@@ -400,11 +437,10 @@ def test_deferral_stays_off_once_the_device_pointer_was_handed_out(monkeypatch):
     d.bind_accum(0, 0)                                   # un-bind: back to library memory, the pointer is still out there
     d.execute(render, n_samples=3)
     assert d.stats()["deferred"] == 0
-    # read the device memory directly, as a caller holding the pointer would (the HIP runtime libmrt_hip.so already uses)
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    seen = np.empty((48, 64, 3), np.float32)
-    assert hip.hipMemcpy(seen.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(48 * 64 * 12), 2) == 0     # DeviceToHost
+    # read the device memory directly, as a caller holding the pointer would: a second context copies it device-to-device
+    reader = Sampler(seed=99).create(render)
+    reader.set_accum_device(ptr, 4)
+    seen = reader.accum()[0]
     eager = Sampler(seed=5)
     eager.execute(render)
     eager.execute(render, n_samples=3)                   # the same two launches, run at once

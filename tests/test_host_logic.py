@@ -400,3 +400,27 @@ def test_fingerprint_sees_bulk_edits_and_is_stable_for_lists():
     g0 = _fingerprint(r2)
     r2.scene.renderer[0].inst[-1][0][0] += 1.0
     assert _fingerprint(r2) != g0
+
+
+def test_level_ordered_triangle_bvh_walk_equals_the_depth_first_one(emu_mod):
+    """F_DEEP (csrc/mrt_scene.h): the triangle-BVH table in level order with explicit child links, of which only a prefix is
+    staged in LDS.  The lane code built that way must render the same bits as the depth-first form, whatever the prefix:
+    1 node (just the root), a few levels, everything; one mesh, several mesh instances behind an instance BVH.  The same for
+    the closest-hit walk that queues every leaf before testing any triangle (F_COLD): the candidate set does not depend on
+    the order of the tests."""
+    from micro_raytracer_amd import scenes
+    import edge_cases
+    cases = [scenes.mesh_scene(res=(48, 27), sample=2, n_tris=400), scenes.kitchen_sink(res=(48, 30), sample=3)]
+    cases += [d for k, d in edge_cases.cases().items() if k.startswith("meshes_tbvh")]
+    for desc in cases:
+        render, h = make_holder(desc)
+        spp = render.rt.sample
+        ref, seg = emu_mod.render(h, 5, spp)
+        n_nodes = emu_mod.layout(h)["n_tbvh_nodes"]
+        n_mesh = sum(1 for o in render.scene.renderer if o.kind == "mesh")
+        got, seg2 = emu_mod.render(h, 5, spp, deep_nodes=0xffffffff)          # F_COLD alone: queued walk, depth-first table
+        assert seg2 == seg and np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(ref).view(np.uint32))
+        for hot in sorted({max(1, n_mesh), 7, 64, n_nodes}):
+            got, seg2 = emu_mod.render(h, 5, spp, deep_nodes=hot)
+            assert seg2 == seg
+            assert np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(ref).view(np.uint32)), hot
