@@ -305,8 +305,12 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         const bool all_ok = fits_any(0u) && !(fc && atoi(fc) && warm_ok);
         // a mesh scene takes the warm level when a 16-wave workgroup fits with stash and leaf queues (closest-hit walks in one
         // round: +18 % on the 967-triangle bench scene); everything else takes the whole scene when it fits
+        // an instance-BVH scene whose texels alone force a single 1024-thread workgroup per CU takes the warm level too: its
+        // kernel is built for 6 waves per SIMD, which 256-thread workgroups around an LDS copy without the texels can supply
+        const bool bvh_no_mesh = (c->pk.features & 16u) != 0u && (c->pk.features & 2u) == 0u;
         if (fd && mesh_walk) cold = kDeep;
         else if (mesh_walk && warm_ok && fits(1024u, kWarm)) cold = kWarm;
+        else if (bvh_no_mesh && warm_ok && !fc && waves(256u, 0u) < 16u && waves(256u, kWarm) >= 24u) cold = kWarm;
         else if (all_ok) cold = 0u;
         else if (warm_ok) cold = kWarm;
         else if (mesh_walk) cold = kDeep;
