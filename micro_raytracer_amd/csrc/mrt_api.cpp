@@ -316,7 +316,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         else if (mesh_walk) cold = kDeep;
         else in_lds = false;
         if (cold == kDeep) {
-            const size_t stash1024 = (size_t)(ST_SLOTS + 8u) * 1024u * sizeof(float);         // lane stash + leaf queues of one 1024-thread workgroup
+            const size_t stash1024 = (size_t)ST_SLOTS * 1024u * sizeof(float);               // lane stash of one 1024-thread workgroup
             PackOpts po; po.tbvh_level_order = true;
             Packed again; std::string err2;
             bool ok2 = pack_scene(desc, again, err2, po) == MRT_OK && again.tbvh_level_order;

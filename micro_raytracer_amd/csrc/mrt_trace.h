@@ -35,7 +35,7 @@ enum : u32 {
 // words of the packed scene a kernel instantiation stages in LDS
 MRT_HD u32 staged_words_for(const Params &P, u32 feat) { return (feat & F_DEEP) ? P.lds_words_hot : ((feat & F_COLD) ? P.lds_words_warm : P.lds_words); }
 // entries of the per-lane leaf queue (LDS, behind the lane stash) of the closest-hit mesh walk; 0: no queue, two leaves in registers
-constexpr u32 leaf_queue_for(u32 feat) { return ((feat & F_COLD) && (feat & F_TRI) && (feat & F_BOX)) ? 8u : 0u; }
+constexpr u32 leaf_queue_for(u32 feat) { return ((feat & F_COLD) && !(feat & F_DEEP) && (feat & F_TRI) && (feat & F_BOX)) ? 8u : 0u; }
 
 // Divergence probe: only the x86 build of tests/emu defines MRT_PROBE(phase); in the kernel it is nothing.
 #ifndef MRT_PROBE
@@ -931,15 +931,21 @@ MRT_HD bool coin(float p, u32 pk, u32 dim)
 // camera focus point).  RegStash keeps it in registers; LdsStash parks it in a per-lane LDS column (slot-major, so
 // lane i always hits bank i) to free VGPRs for the traversal loop without the compiler spilling to scratch,
 // whose write-backs would show up as HBM traffic.  volatile: the values must really live in LDS across the loop.
-enum : u32 { ST_ACC = 0, ST_FOCUS = 3, ST_PIXKEY = 6, ST_CHUNK = 7, ST_SEND = 8, ST_WORD = 9, ST_SLOTS = 10 };
+enum : u32 { ST_ACC = 0, ST_FOCUS = 3, ST_PIXKEY = 6, ST_CHUNK = 7, ST_SEND = 8, ST_WORD = 9, ST_SLOTS = 10, ST_T = 10, ST_L = 13, ST_SLOTS_TL = 16 };
+// The kernels bound to 6 waves per SIMD (80 VGPRs: instance BVH, no mesh code, warm staging) also park the path's throughput
+// and radiance (T, L: touched between segments only) in the stash instead of leaving them to the register allocator's spills.
+constexpr bool tl_in_stash(u32 feat) { return (feat & F_COLD) && (feat & F_BVH) && !(feat & F_TRI); }
+constexpr u32 stash_slots_for(u32 feat) { return tl_in_stash(feat) ? (u32)ST_SLOTS_TL : (u32)ST_SLOTS; }
 struct RegStash {
-    float v[ST_SLOTS];
+    static constexpr bool in_lds = false;
+    float v[ST_SLOTS_TL];
     MRT_HD void put(u32 slot, float x) { v[slot] = x; }
     MRT_HD float get(u32 slot) const { return v[slot]; }
 };
 #if defined(__HIPCC__) || defined(__HIP__)
 template <u32 THREADS>
 struct LdsStash {
+    static constexpr bool in_lds = true;
     lds_vfloat *base;         // &lds_stash[tid]; slot-major columns of THREADS floats
     MRT_HD void put(u32 slot, float x) { base[slot * THREADS] = x; }
     MRT_HD float get(u32 slot) const { return base[slot * THREADS]; }
@@ -993,7 +999,14 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     V3 csum = v3(0.0f, 0.0f, 0.0f);
     u32 pk = 0, b = 0;
     V3 o = v3(0, 0, 0), d = v3(0, 1, 0);
-    V3 T = v3(1, 1, 1), L = v3(0, 0, 0);
+    // path throughput T and radiance L: registers, or (tl_in_stash) two stash columns
+    constexpr bool kTL = tl_in_stash(FEAT) && Stash::in_lds;
+    V3 T_ = v3(1, 1, 1), L_ = v3(0, 0, 0);
+    auto getT = [&]() { if constexpr (kTL) return st_get3(st, ST_T); else return T_; };
+    auto getL = [&]() { if constexpr (kTL) return st_get3(st, ST_L); else return L_; };
+    auto setT = [&](V3 v) { if constexpr (kTL) st_put3(st, ST_T, v); else T_ = v; };
+    auto setL = [&](V3 v) { if constexpr (kTL) st_put3(st, ST_L, v); else L_ = v; };
+    setT(v3(1, 1, 1)); setL(v3(0, 0, 0));
     float pwr = 1.0f;
     u32 seg = 0;
     if (alive) {                                 // first sample of this lane: every lane of the wavefront is here
@@ -1017,7 +1030,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
         V3 base = o;                             // the point it leaves from (hit point, or lens position)
         if (!trace<false, FEAT>(S, ray, h)) {
             // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
-            contrib = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(L, hadam(T, sky_init));
+            contrib = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(getL(), hadam(getT(), sky_init));
             ended = true;
         } else {
             MRT_PROBE(PH_SHADE);
@@ -1068,7 +1081,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
             const float emit = surf_scalar<FEAT>(S, sfh, MAP_EMIT, MAT_EMIT);
             if (coin(emit, pk, dim_of(b, SL_EMIT_COIN))) {
                 MRT_PROBE(PH_EMIT_END);
-                contrib = add(L, hadam(T, color));
+                contrib = add(getL(), hadam(getT(), color));
                 ended = true;
             } else {
                 // direct light, visibility from hit0 (src/rt.rs:1027-1046), shading at the recorded hit (:973-987)
@@ -1102,13 +1115,13 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                         l_col = add(l_col, term);
                     }
                     // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
-                    L = add(L, hadam(T, muls(l_col, pwr)));
+                    setL(add(getL(), hadam(getT(), muls(l_col, pwr))));
                 }
-                T = hadam(T, muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr));
+                setT(hadam(getT(), muls(v3(0.5f + color.x, 0.5f + color.y, 0.5f + color.z), pwr)));
                 pwr = pwr * P.q;                                        // Ray::cast, src/rt.rs:571
                 ++b;
                 if (b > P.bounce) {          // src/rt.rs:1018
-                    contrib = add(L, hadam(T, sky_init));
+                    contrib = add(getL(), hadam(getT(), sky_init));
                     ended = true;
                 }
             }
@@ -1140,7 +1153,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                 pk = mix32(f2u(st.get(ST_PIXKEY)) + s * kGold);
                 base = lens_pos(P, pk);
                 X = sub(st_get3(st, ST_FOCUS), base);               // new_dir before .norm()
-                T = v3(1.0f, 1.0f, 1.0f); L = v3(0.0f, 0.0f, 0.0f);
+                setT(v3(1.0f, 1.0f, 1.0f)); setL(v3(0.0f, 0.0f, 0.0f));
                 pwr = 1.0f; b = 0;
                 from_camera = true;
             }
