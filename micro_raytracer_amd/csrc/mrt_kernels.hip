@@ -35,6 +35,9 @@ constexpr bool lds_stash_for(bool scene_in_lds, int block_threads, u32 feat)
     return block_threads != 512 && !(feat & F_NOSTASH);
 #endif
 }
+#ifndef MRT_BVH_WAVES
+#define MRT_BVH_WAVES 6
+#endif
 constexpr int waves_for(u32 feat)
 {
 #ifdef MRT_WAVES_PER_EU
@@ -44,7 +47,7 @@ constexpr int waves_for(u32 feat)
     // resident wavefronts at one 1024-thread workgroup): bound to 6 waves per SIMD (80 VGPRs, a few spills).  These walks
     // wait on dependent LDS reads, not on issue slots: the Minecraft-shaped scene gains 12 % with 5 waves, 16 % with 6, 17 %
     // with 7-8 over the 4 its 114 VGPRs allow.  The mesh kernels stay at 4: their LDS footprint caps them at 16 waves per CU.
-    if ((feat & F_COLD) && (feat & F_BVH) && !(feat & F_TRI)) return 6;
+    if ((feat & F_COLD) && (feat & F_BVH) && !(feat & F_TRI)) return MRT_BVH_WAVES;
     return (feat & ~F_BOX) == 0 ? 7 : ((feat & (F_LIGHTS | F_TRI | F_BVH)) == 0 ? 6 : 4);      // the BVH walks need their registers more than two extra waves
 #endif
 }
