@@ -89,10 +89,11 @@ constexpr size_t kTwoCopies = 68u * 1024u;          // <= this: two 256-thread w
 constexpr size_t kStash256 = 10u * 1024u + 256u;     // lane stash of a 256-thread workgroup (ST_SLOTS * 256 * 4 B, rounded up)
 constexpr size_t kOneCopyStash = 118u * 1024u;      // <= this: one 1024-thread workgroup with its 40 KB stash fits a CU
 constexpr size_t kSmallScene = 6u * 1024u;          // <= this: single-wave workgroups are allowed (24 LDS copies per CU)
-// Sample-split until the launch has ~15 rounds of 32 waves per CU: shorter wavefronts balance the tail of a launch (tiles
+// Sample-split until the launch has ~25 rounds of 32 waves per CU: shorter wavefronts balance the tail of a launch (tiles
 // differ in path length).  Measured on the 1080p x 1024 spp Cornell box (tests/gpu_shard_probe.py): whole frame 328 -> 315 ms
-// with 4 lanes per pixel, one shard of 8 GPUs 47.1 -> 42.4 ms with 16.
-constexpr unsigned long long kSplitTargetWaves = 120000ull;
+// with 4 lanes per pixel, one shard of 8 GPUs 47.1 -> 42.4 ms with 16; round 3, persistent 256-thread workgroups: 1 / 2 / 4 / 8
+// lanes per pixel 292.9 / 274.7 / 267.7 / 265.7 ms, hence 8 at 1080p (the target was 120 000 wavefronts: 4).
+constexpr unsigned long long kSplitTargetWaves = 200000ull;
 // A sample-split launch writes one f32x3 chunk sum per pixel per 16 samples; the buffer is bounded by cutting one
 // mrt_execute into several launches of at most this many sample chunks (1024 samples) and this many bytes.  Launch
 // boundaries are chunk boundaries, so the canonical accumulation order -- and every bit -- is unchanged.
@@ -156,7 +157,10 @@ struct mrt_ctx {
     bool whole_frame = true;             // accumulator holds every row (shard_count == 1 or after set_accum)
     float *d_full = nullptr;             // [nh][nw][3] when a sharded context received a full frame
     u32 full_count = 0;
-    u32 block_threads = 256;
+    u32 block_threads = 256;             // workgroup size of the batched launches
+    u32 small_threads = 0;               // != 0: workgroup size of launches of less than one sample chunk (the per-sample calls of the
+                                         // reference's callers): single-wave workgroups, one per tile, no tile counter to reset
+    u32 persist_grid = 0;                // persistent grid of the batched shape
     bool scene_in_lds = true;
     // img resources (lazy)
     unsigned char *d_ss = nullptr, *d_out = nullptr;
@@ -351,7 +355,11 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     u32 want = 256u, marker = cold;
     if (in_lds) {
         const size_t w256 = waves(256u, cold), w512 = waves(512u, cold), w1024 = waves(1024u, cold);
-        if (w256 >= 16u) want = (blob_bytes <= kSmallScene && !cold) ? 64u : 256u;      // single-wave workgroups schedule finest: +1 % on the Cornell scenes at any frame size
+        // small scenes (<= 6 KB: ~29 single-wave workgroups per CU): batched launches take 256-thread persistent workgroups
+        // (four waves around one LDS copy: 32 waves per CU fit, +4 % on the headline frame, +7 % with the 8-wave build of the
+        // plane / sphere kernel, +4 % on CornellBox2), launches of less than one sample chunk single-wave workgroups (a
+        // one-sample pass through the persistent shape: 0.56 ms against 0.39)
+        if (w256 >= 16u) { want = 256u; if (blob_bytes <= kSmallScene && !cold) c->small_threads = 64u; }
         else if (w512 >= 16u) want = 512u;
         else if (w1024 >= 16u) want = 1024u;
         else if (w256 >= w512 && w256 >= 8u) want = 256u;
@@ -360,7 +368,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     }
     if (force && in_lds) {
         const u32 f = (u32)atoi(force);
-        if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; } }
+        if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; c->small_threads = 0u; } }
     }
     c->pk.features = (c->pk.features & 31u) | marker;
     c->block_threads = want;
@@ -382,7 +390,8 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         size_t per_cu = 32u / (c->block_threads / 64u);
         if (lds && kLdsLimit / lds < per_cu) per_cu = kLdsLimit / lds;
         if (per_cu < 1u) per_cu = 1u;
-        c->P.persist_grid = c->block_threads > 64u && !getenv("MRT_NO_PERSIST") ? (u32)(n_cu * per_cu) : 0u;
+        c->persist_grid = c->block_threads > 64u && !getenv("MRT_NO_PERSIST") ? (u32)(n_cu * per_cu) : 0u;
+        c->P.persist_grid = c->persist_grid;
     }
     c->count_segments = (opts->flags & MRT_FLAG_COUNT_SEGMENTS) != 0;
     c->event_timing = (opts->flags & MRT_FLAG_NO_EVENT_TIMING) == 0;
@@ -505,14 +514,16 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
     c->stats_pending = false; c->ev_used = 0;
     if (!(n_samples && c->local_rows)) return MRT_OK;
     if (c->count_segments) HIP_TRY(hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
-    const bool persist = c->block_threads > 64u && c->P.persist_grid != 0u;
     // sample split: spread a small frame over more wavefronts, one lane per (pixel, every k-th sample chunk)
     const u32 first_chunk = c->count / kChunk;
     const u32 end_chunk = (c->count + n_samples - 1u) / kChunk + 1u;
     const u32 n_chunks = end_chunk - first_chunk;
     const unsigned long long wave_tiles = (unsigned long long)((c->pk.nw + 7) / 8) * ((c->local_rows + 7) / 8);
     u32 k_split = 1;
-    while (k_split * 2u <= n_chunks && k_split < 16u && wave_tiles * k_split < kSplitTargetWaves) k_split *= 2u;
+    // (a frame of 100 000 wave tiles or more -- 4K -- has its 25 rounds without splitting: CornellBox2 at 3840x2160 loses 1.6 %
+    // to a second lane per pixel, 985 -> 1001 ms)
+    const unsigned long long split_target = wave_tiles >= 100000ull ? 0ull : kSplitTargetWaves;
+    while (k_split * 2u <= n_chunks && k_split < 16u && wave_tiles * k_split < split_target) k_split *= 2u;
     if (c->knob_k_split) { k_split = c->knob_k_split; while (k_split > n_chunks) k_split /= 2u; }
     const size_t plane = (size_t)c->padded_rows * c->pk.nw * 3;
     u32 cap = kMaxChunksPerLaunch;                       // chunks per launch
@@ -551,9 +562,18 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
         c->P.k_split = ks;
         while (c->event_timing && c->evs.size() < (size_t)c->ev_used + 3u) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->evs.push_back(e); }
         hipEvent_t *ev = c->event_timing ? &c->evs[c->ev_used] : nullptr;
+        // the shape of this launch: less than one sample chunk goes through the small shape when the scene has one
+        const u32 bt = (c->small_threads && stop - base < kChunk) ? c->small_threads : c->block_threads;
+        c->P.tiles_x = bt == 64u ? 1u : (bt == 256u ? 2u : 4u);
+        c->P.tiles_y = bt == 64u ? 1u : (bt == 1024u ? 4u : 2u);
+        c->P.persist_grid = bt == c->block_threads ? c->persist_grid : 0u;
+        const bool persist = bt > 64u && c->P.persist_grid != 0u;
         if (persist) HIP_TRY(hipMemsetAsync(c->P.tile_counter, 0, sizeof(u32), c->stream));
         if (c->event_timing) HIP_TRY(hipEventRecord(ev[0], c->stream));
-        HIP_TRY(launch_pt(c->P, c->block_threads, c->scene_in_lds, c->pk.features, c->stream));
+        HIP_TRY(launch_pt(c->P, bt, c->scene_in_lds, c->pk.features, c->stream));
+        c->stats.block_threads = bt;
+        c->stats.lds_bytes = (u32)pt_lds_bytes(c->P, bt, c->scene_in_lds, c->pk.features);
+        c->stats.kernel_features = pt_instantiation(bt, c->scene_in_lds, c->pk.features);
         if (c->event_timing) HIP_TRY(hipEventRecord(ev[1], c->stream));
         if (ks > 1u) HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_partial, (size_t)c->local_rows * c->pk.nw * 3, plane, nc, c->stream));
         if (c->event_timing) { HIP_TRY(hipEventRecord(ev[2], c->stream)); c->ev_used += 3u; }

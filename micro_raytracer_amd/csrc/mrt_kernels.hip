@@ -38,11 +38,16 @@ constexpr bool lds_stash_for(bool scene_in_lds, int block_threads, u32 feat)
 #ifndef MRT_BVH_WAVES
 #define MRT_BVH_WAVES 6
 #endif
-constexpr int waves_for(u32 feat)
+constexpr int waves_for(u32 feat, int block_threads)
 {
 #ifdef MRT_WAVES_PER_EU
     return MRT_WAVES_PER_EU;
 #else
+    // Planes and spheres only (the Cornell box), 256-thread workgroups: 8 waves per SIMD (64 VGPRs).  With single-wave
+    // workgroups every wavefront brings its own 5.5 KB of LDS (scene copy + stash) and the CU tops out at 29 of them, so a
+    // bound of 8 only bought spills there (-3 %); four waves around one copy need 13 KB and all 32 fit: 7.42 -> 7.93
+    // Gsamples/s on the headline frame (7.71 with the 7-wave build of the same shape).  With boxes (CornellBox2) 8 loses to 7.
+    if (feat == 0u && block_threads == 256) return 8;
     // The instance-BVH kernels without mesh code, warm staging (F_COLD: texels in global memory, so the LDS no longer caps the
     // resident wavefronts at one 1024-thread workgroup): bound to 6 waves per SIMD (80 VGPRs, a few spills).  These walks
     // wait on dependent LDS reads, not on issue slots: the Minecraft-shaped scene gains 12 % with 5 waves, 16 % with 6, 17 %
@@ -53,7 +58,7 @@ constexpr int waves_for(u32 feat)
 }
 
 template <bool SCENE_IN_LDS, int BLOCK_THREADS, u32 FEAT>
-__global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT)) pt_megakernel(const Params P, const u32 *__restrict__ blob_g)
+__global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT, BLOCK_THREADS)) pt_megakernel(const Params P, const u32 *__restrict__ blob_g)
 {
     extern __shared__ uint4 lds_blob[];
     const float *F;
