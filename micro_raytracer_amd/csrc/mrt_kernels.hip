@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT, BLOCK_THREADS))
     constexpr bool kStash = lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS, FEAT);
     S.lq = nullptr; S.lq_stride = BLOCK_THREADS;
     if constexpr (leaf_queue_for(FEAT) != 0u)
-        S.lq = (void *)(reinterpret_cast<float *>(lds_blob + stash_base4) + (kStash ? stash_slots_for(FEAT) * BLOCK_THREADS : 0u) + threadIdx.x);
+        S.lq = (void *)(reinterpret_cast<float *>(lds_blob + stash_base4) + (kStash ? stash_slots_for(FEAT, BLOCK_THREADS) * BLOCK_THREADS : 0u) + threadIdx.x);
     u32 segments = 0;
     // one 8x8 tile of shard-local rows for this wavefront, lane k of the sample split
     auto do_tile = [&](u32 tx, u32 ty, u32 k) {
@@ -292,7 +292,7 @@ size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 f
     const u32 inst = pt_instantiation(block_threads, scene_in_lds, features);      // what the kernel itself sees as FEAT
     size_t lds = scene_in_lds ? (size_t)staged_words_for(P, inst) * 4u : 0u;
     lds = (lds + 15u) & ~(size_t)15u;
-    if (lds_stash_for(scene_in_lds, (int)block_threads, inst)) lds += (size_t)stash_slots_for(inst) * block_threads * sizeof(float);
+    if (lds_stash_for(scene_in_lds, (int)block_threads, inst)) lds += (size_t)stash_slots_for(inst, block_threads) * block_threads * sizeof(float);
     lds += (size_t)leaf_queue_for(inst) * block_threads * sizeof(u32);
     return lds;
 }

@@ -934,10 +934,12 @@ MRT_HD bool coin(float p, u32 pk, u32 dim)
 enum : u32 { ST_ACC = 0, ST_FOCUS = 3, ST_PIXKEY = 6, ST_CHUNK = 7, ST_SEND = 8, ST_WORD = 9, ST_SLOTS = 10, ST_T = 10, ST_L = 13, ST_SLOTS_TL = 16 };
 // The kernels bound to 6 waves per SIMD (80 VGPRs: instance BVH, no mesh code, warm staging) also park the path's throughput
 // and radiance (T, L: touched between segments only) in the stash instead of leaving them to the register allocator's spills.
-constexpr bool tl_in_stash(u32 feat) { return (feat & F_COLD) && (feat & F_BVH) && !(feat & F_TRI); }
-constexpr u32 stash_slots_for(u32 feat) { return tl_in_stash(feat) ? (u32)ST_SLOTS_TL : (u32)ST_SLOTS; }
+// (The 8-wave plane / sphere kernel of the 256-thread shape, 64 VGPRs + 24 B of scratch, gains nothing from it: 7949 vs 7987.)
+constexpr bool tl_in_stash(u32 feat, u32 /*threads*/) { return (feat & F_COLD) && (feat & F_BVH) && !(feat & F_TRI); }
+constexpr u32 stash_slots_for(u32 feat, u32 threads) { return tl_in_stash(feat, threads) ? (u32)ST_SLOTS_TL : (u32)ST_SLOTS; }
 struct RegStash {
     static constexpr bool in_lds = false;
+    static constexpr u32 threads = 0;
     float v[ST_SLOTS_TL];
     MRT_HD void put(u32 slot, float x) { v[slot] = x; }
     MRT_HD float get(u32 slot) const { return v[slot]; }
@@ -946,6 +948,7 @@ struct RegStash {
 template <u32 THREADS>
 struct LdsStash {
     static constexpr bool in_lds = true;
+    static constexpr u32 threads = THREADS;
     lds_vfloat *base;         // &lds_stash[tid]; slot-major columns of THREADS floats
     MRT_HD void put(u32 slot, float x) { base[slot * THREADS] = x; }
     MRT_HD float get(u32 slot) const { return base[slot * THREADS]; }
@@ -1000,7 +1003,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     u32 pk = 0, b = 0;
     V3 o = v3(0, 0, 0), d = v3(0, 1, 0);
     // path throughput T and radiance L: registers, or (tl_in_stash) two stash columns
-    constexpr bool kTL = tl_in_stash(FEAT) && Stash::in_lds;
+    constexpr bool kTL = Stash::in_lds && tl_in_stash(FEAT, Stash::threads);
     V3 T_ = v3(1, 1, 1), L_ = v3(0, 0, 0);
     auto getT = [&]() { if constexpr (kTL) return st_get3(st, ST_T); else return T_; };
     auto getL = [&]() { if constexpr (kTL) return st_get3(st, ST_L); else return L_; };
