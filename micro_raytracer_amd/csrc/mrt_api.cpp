@@ -158,8 +158,8 @@ struct mrt_ctx {
     float *d_full = nullptr;             // [nh][nw][3] when a sharded context received a full frame
     u32 full_count = 0;
     u32 block_threads = 256;             // workgroup size of the batched launches
-    u32 small_threads = 0;               // != 0: workgroup size of launches of less than one sample chunk (the per-sample calls of the
-                                         // reference's callers): single-wave workgroups, one per tile, no tile counter to reset
+    bool small_plain_grid = false;       // launches of less than one sample chunk (the per-sample calls of the reference's callers) take
+                                         // the plain grid, one workgroup per 2x2 wave tiles: no tile counter to reset and draw from
     u32 persist_grid = 0;                // persistent grid of the batched shape
     bool scene_in_lds = true;
     // img resources (lazy)
@@ -355,11 +355,11 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     u32 want = 256u, marker = cold;
     if (in_lds) {
         const size_t w256 = waves(256u, cold), w512 = waves(512u, cold), w1024 = waves(1024u, cold);
-        // small scenes (<= 6 KB: ~29 single-wave workgroups per CU): batched launches take 256-thread persistent workgroups
-        // (four waves around one LDS copy: 32 waves per CU fit, +4 % on the headline frame, +7 % with the 8-wave build of the
-        // plane / sphere kernel, +4 % on CornellBox2), launches of less than one sample chunk single-wave workgroups (a
-        // one-sample pass through the persistent shape: 0.56 ms against 0.39)
-        if (w256 >= 16u) { want = 256u; if (blob_bytes <= kSmallScene && !cold) c->small_threads = 64u; }
+        // small scenes (<= 6 KB: ~29 single-wave workgroups per CU would fit): 256-thread workgroups all the same -- four waves
+        // around one LDS copy, so that 32 waves per CU fit: +4 % on the headline frame, +7 % with the 8-wave build of the plane /
+        // sphere kernel, +4 % on CornellBox2 -- persistent for batched launches, on the plain grid for launches of less than
+        // one sample chunk (a one-sample pass over the 1080p frame: persistent 0.56 ms, single-wave workgroups 0.39, this 0.37)
+        if (w256 >= 16u) { want = 256u; c->small_plain_grid = blob_bytes <= kSmallScene && !cold; }
         else if (w512 >= 16u) want = 512u;
         else if (w1024 >= 16u) want = 1024u;
         else if (w256 >= w512 && w256 >= 8u) want = 256u;
@@ -368,7 +368,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     }
     if (force && in_lds) {
         const u32 f = (u32)atoi(force);
-        if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; c->small_threads = 0u; } }
+        if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; c->small_plain_grid = false; } }
     }
     c->pk.features = (c->pk.features & 31u) | marker;
     c->block_threads = want;
@@ -562,11 +562,8 @@ static int exec_launch(mrt_ctx *c, uint32_t n_samples)
         c->P.k_split = ks;
         while (c->event_timing && c->evs.size() < (size_t)c->ev_used + 3u) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->evs.push_back(e); }
         hipEvent_t *ev = c->event_timing ? &c->evs[c->ev_used] : nullptr;
-        // the shape of this launch: less than one sample chunk goes through the small shape when the scene has one
-        const u32 bt = (c->small_threads && stop - base < kChunk) ? c->small_threads : c->block_threads;
-        c->P.tiles_x = bt == 64u ? 1u : (bt == 256u ? 2u : 4u);
-        c->P.tiles_y = bt == 64u ? 1u : (bt == 1024u ? 4u : 2u);
-        c->P.persist_grid = bt == c->block_threads ? c->persist_grid : 0u;
+        const u32 bt = c->block_threads;
+        c->P.persist_grid = (c->small_plain_grid && stop - base < kChunk) ? 0u : c->persist_grid;
         const bool persist = bt > 64u && c->P.persist_grid != 0u;
         if (persist) HIP_TRY(hipMemsetAsync(c->P.tile_counter, 0, sizeof(u32), c->stream));
         if (c->event_timing) HIP_TRY(hipEventRecord(ev[0], c->stream));
