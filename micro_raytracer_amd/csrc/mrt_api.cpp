@@ -85,10 +85,7 @@ Rccl g_rccl;
 constexpr int kNcclFloat = 7;                        // ncclFloat32, rccl.h:466
 
 constexpr size_t kLdsLimit = 160u * 1024u;          // LDS per CU on gfx950
-constexpr size_t kTwoCopies = 68u * 1024u;          // <= this: two 256-thread workgroups (two LDS copies + their stash) fit a CU
-constexpr size_t kStash256 = 10u * 1024u + 256u;     // lane stash of a 256-thread workgroup (ST_SLOTS * 256 * 4 B, rounded up)
-constexpr size_t kOneCopyStash = 118u * 1024u;      // <= this: one 1024-thread workgroup with its 40 KB stash fits a CU
-constexpr size_t kSmallScene = 6u * 1024u;          // <= this: single-wave workgroups are allowed (24 LDS copies per CU)
+constexpr size_t kSmallScene = 6u * 1024u;          // <= this: launches of less than one sample chunk take the plain grid (no tile counter)
 // Sample-split until the launch has ~25 rounds of 32 waves per CU: shorter wavefronts balance the tail of a launch (tiles
 // differ in path length).  Measured on the 1080p x 1024 spp Cornell box (tests/gpu_shard_probe.py): whole frame 328 -> 315 ms
 // with 4 lanes per pixel, one shard of 8 GPUs 47.1 -> 42.4 ms with 16; round 3, persistent 256-thread workgroups: 1 / 2 / 4 / 8
@@ -283,8 +280,8 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     //   none    everything through L2 (the small tables themselves do not fit).
     // Launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
     // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most:
-    //   256 threads (2x2 wave tiles of 8x8 pixels) + 10 KB lane stash per copy of the scene;
-    //   64 threads instead when the scene is small enough for ~29 LDS copies per CU (<= 6 KB);
+    //   256 threads (2x2 wave tiles of 8x8 pixels) + 10 KB lane stash per copy of the scene (64-thread workgroups -- one
+    //   wavefront, its own 5.5 KB of LDS -- served small scenes until round 3 and remain as a forced shape for the tests);
     //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves.
     // Environment (experiments, tests; read here, once): MRT_COLD=0/1 forbids / forces the warm level, MRT_DEEP_NODES=n forces
     // the deep level with n staged nodes, MRT_SCENE_IN_L2 forces none, MRT_BLOCK_THREADS forces a workgroup size.
@@ -308,7 +305,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
         const bool warm_ok = has_warm && fits_any(kWarm) && !(fc && !atoi(fc));
         const bool all_ok = fits_any(0u) && !(fc && atoi(fc) && warm_ok);
         // a mesh scene takes the warm level when a 16-wave workgroup fits with stash and leaf queues (closest-hit walks in one
-        // round: +18 % on the 967-triangle bench scene); everything else takes the whole scene when it fits
+        // round: VALU -8.5 %, time -2 % on the 967-triangle bench scene); everything else takes the whole scene when it fits;
         // an instance-BVH scene whose texels alone force a single 1024-thread workgroup per CU takes the warm level too: its
         // kernel is built for 6 waves per SIMD, which 256-thread workgroups around an LDS copy without the texels can supply
         const bool bvh_no_mesh = (c->pk.features & 16u) != 0u && (c->pk.features & 2u) == 0u;
