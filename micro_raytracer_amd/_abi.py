@@ -80,6 +80,13 @@ class Stats(C.Structure):
                 ("reduce_ms", C.c_double), ("kernel_features", C.c_uint32), ("scene_in_lds", C.c_uint32)]
 
 
+class Plan(C.Structure):
+    _fields_ = [("staging", C.c_uint32), ("block_threads", C.c_uint32), ("lds_bytes", C.c_uint32), ("staged_bytes", C.c_uint32),
+                ("scene_bytes", C.c_uint32), ("kernel_features", C.c_uint32), ("tbvh_nodes", C.c_uint32), ("tbvh_hot_nodes", C.c_uint32),
+                ("small_plain_grid", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+STAGING = ("all", "warm", "deep", "none")
 MAP_SLOTS = ("tex", "rmap", "mmap", "gmap", "omap", "emap")
 
 

@@ -14,7 +14,7 @@ SYMBOLS = (
     "mrt_create", "mrt_destroy", "mrt_execute", "mrt_dims", "mrt_accum", "mrt_accum_local", "mrt_accum_device_ptr",
     "mrt_set_accum", "mrt_img", "mrt_img_ss", "mrt_reset", "mrt_get_stats", "mrt_last_error", "mrt_last_status",
     "mrt_abi_version", "mrt_device_count", "mrt_selftest_math", "mrt_padded_rows", "mrt_bind_accum",
-    "mrt_set_accum_device", "mrt_save_image", "mrt_selftest_sweep",
+    "mrt_set_accum_device", "mrt_save_image", "mrt_selftest_sweep", "mrt_plan_launch",
 )
 
 
@@ -68,6 +68,7 @@ def lib():
     L.mrt_bind_accum.argtypes = [vp, vp, C.c_size_t]
     L.mrt_set_accum_device.argtypes = [vp, vp, u32]
     L.mrt_save_image.argtypes = [C.c_char_p, u8p, u32, u32]
+    L.mrt_plan_launch.argtypes = [vp, C.POINTER(_abi.Plan)]
     L.mrt_selftest_math.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p, C.c_size_t]
     L.mrt_selftest_sweep.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, u32, C.POINTER(C.c_uint64), f32p]
     _LIB = L
@@ -78,6 +79,16 @@ def check(rc):
     if rc != 0:
         L = lib()
         raise MrtError(rc, L.mrt_last_error().decode())
+
+
+def plan_launch(render_or_holder):
+    """What mrt_create would stage in LDS for this scene and the launch shape it would take (host only, no device needed)."""
+    h = render_or_holder if hasattr(render_or_holder, "ptr") else _abi.build_desc(render_or_holder)
+    pl = _abi.Plan()
+    check(lib().mrt_plan_launch(C.cast(h.ptr(), C.c_void_p), C.byref(pl)))
+    d = {k: getattr(pl, k) for k, _ in pl._fields_ if k != "reserved"}
+    d["staging"] = _abi.STAGING[pl.staging]
+    return d
 
 
 def selftest_math(op, a, b=None, device=0):

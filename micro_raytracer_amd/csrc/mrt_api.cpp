@@ -219,6 +219,121 @@ int mrt_device_count(void)
     return n;
 }
 
+
+namespace {
+
+// What a context stages in LDS and the shape of its launches: a pure function of the packed scene (and of the experiment /
+// test knobs of the environment) -- no device involved, so that the policy can be checked without one (mrt_plan_launch).
+struct Plan {
+    bool in_lds = true;
+    u32 block_threads = 256;
+    bool small_plain_grid = false;
+    size_t staged_bytes = 0;
+};
+
+void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
+{
+    // ---- what is staged in LDS, and the launch shape -------------------------------------------------------------------
+    // LDS per workgroup = staged scene + lane stash (+ the mesh kernels' leaf queues): pt_lds_bytes knows.  Staging levels:
+    //   all     the whole packed scene (minus the octree leaf lists);
+    //   warm    F_COLD: membership tables and texels stay in global memory (touched at most once per shaded hit); the mesh
+    //           kernels spend the freed LDS on a per-lane leaf queue, so a mesh scene prefers this level when it fits;
+    //   deep    F_COLD | F_DEEP: meshes beyond the LDS.  The scene is packed again with the triangle-BVH table in level order
+    //           and as many of its first nodes -- the top levels of every tree -- as fit next to the small tables are staged;
+    //           deeper nodes and the triangles are read from global memory too;
+    //   none    everything through L2 (the small tables themselves do not fit).
+    // Launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
+    // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most:
+    //   256 threads (2x2 wave tiles of 8x8 pixels) + 10 KB lane stash per copy of the scene (64-thread workgroups -- one
+    //   wavefront, its own 5.5 KB of LDS -- served small scenes until round 3 and remain as a forced shape for the tests);
+    //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves.
+    // Environment (experiments, tests; read here, once): MRT_COLD=0/1 forbids / forces the warm level, MRT_DEEP_NODES=n forces
+    // the deep level with n staged nodes, MRT_SCENE_IN_L2 forces none, MRT_BLOCK_THREADS forces a workgroup size.
+    const bool no_lds = getenv("MRT_SCENE_IN_L2") != nullptr;
+    const char *force = getenv("MRT_BLOCK_THREADS");
+    const bool mesh_walk = pk.n_tbvh_nodes != 0u && (pk.features & 3u) == 3u;
+    auto lds_of = [&](u32 shape, u32 marker) { return pt_lds_bytes(pk.P, shape, true, (pk.features & 31u) | marker); };
+    auto fits = [&](u32 shape, u32 marker) { return lds_of(shape, marker) <= kLdsLimit; };
+    auto fits_any = [&](u32 marker) { return fits(256u, marker) || fits(512u, marker) || fits(1024u, marker); };
+    auto waves = [&](u32 shape, u32 marker) {            // resident wavefronts per CU of this shape, LDS-wise
+        const size_t l = lds_of(shape, marker);
+        return l > kLdsLimit ? (size_t)0 : (shape / 64u) * (kLdsLimit / (l ? l : 1));
+    };
+    constexpr u32 kWarm = 64u, kDeep = 64u | 128u;       // F_COLD, F_COLD | F_DEEP
+    const bool has_warm = pk.P.lds_words_warm < pk.P.lds_words;
+    u32 cold = 0u;
+    bool in_lds = !no_lds;
+    if (in_lds) {
+        const char *fc = getenv("MRT_COLD");
+        const char *fd = getenv("MRT_DEEP_NODES");
+        const bool warm_ok = has_warm && fits_any(kWarm) && !(fc && !atoi(fc));
+        const bool all_ok = fits_any(0u) && !(fc && atoi(fc) && warm_ok);
+        // a mesh scene takes the warm level when a 16-wave workgroup fits with stash and leaf queues (closest-hit walks in one
+        // round: VALU -8.5 %, time -2 % on the 967-triangle bench scene); everything else takes the whole scene when it fits;
+        // an instance-BVH scene whose texels alone force a single 1024-thread workgroup per CU takes the warm level too: its
+        // kernel is built for 6 waves per SIMD, which 256-thread workgroups around an LDS copy without the texels can supply
+        const bool bvh_no_mesh = (pk.features & 16u) != 0u && (pk.features & 2u) == 0u;
+        if (fd && mesh_walk) cold = kDeep;
+        else if (mesh_walk && warm_ok && fits(1024u, kWarm)) cold = kWarm;
+        else if (bvh_no_mesh && warm_ok && !fc && waves(256u, 0u) < 16u && waves(256u, kWarm) >= 24u) cold = kWarm;
+        else if (all_ok) cold = 0u;
+        else if (warm_ok) cold = kWarm;
+        else if (mesh_walk) cold = kDeep;
+        else in_lds = false;
+        if (cold == kDeep) {
+            const size_t stash1024 = (size_t)ST_SLOTS * 1024u * sizeof(float);               // lane stash of one 1024-thread workgroup
+            PackOpts po; po.tbvh_level_order = true;
+            Packed again; std::string err2;
+            bool ok2 = pack_scene(desc, again, err2, po) == MRT_OK && again.tbvh_level_order;
+            const size_t front = ok2 ? (size_t)again.P.off_tbvh * 4 : 0;                         // everything hot in front of the node table
+            ok2 = ok2 && front + stash1024 + 1024 < kLdsLimit;
+            if (ok2) {
+                const size_t room = (kLdsLimit - stash1024 - 1024 - front) / (BVH_WORDS * 4);
+                size_t n = fd ? (size_t)strtoul(fd, nullptr, 10) : room;
+                if (n > room) n = room;
+                if (n > again.n_tbvh_nodes) n = again.n_tbvh_nodes;
+                const u32 n_mesh = (again.P.off_node - again.P.off_mesh) / MESH_WORDS;
+                ok2 = n >= n_mesh && n_mesh > 0u;            // every root is staged (the walk reads it from LDS unconditionally)
+                if (ok2) {
+                    const u32 keep = pk.features;
+                    pk = again;
+                    pk.features = keep;
+                    pk.P.n_tbvh_hot = (u32)n;
+                    pk.P.lds_words_hot = (pk.P.off_tbvh + (u32)n * BVH_WORDS + 3u) & ~3u;
+                }
+            }
+            if (!ok2) { cold = 0u; in_lds = false; }
+        }
+    }
+    const size_t full_bytes = (size_t)pk.P.lds_words * 4;
+    const size_t blob_bytes = in_lds ? (size_t)staged_words_for(pk.P, cold) * 4 : full_bytes;
+    u32 want = 256u, marker = cold;
+    pl.small_plain_grid = false;
+    if (in_lds) {
+        const size_t w256 = waves(256u, cold), w512 = waves(512u, cold), w1024 = waves(1024u, cold);
+        // small scenes (<= 6 KB: ~29 single-wave workgroups per CU would fit): 256-thread workgroups all the same -- four waves
+        // around one LDS copy, so that 32 waves per CU fit: +4 % on the headline frame, +7 % with the 8-wave build of the plane /
+        // sphere kernel, +4 % on CornellBox2 -- persistent for batched launches, on the plain grid for launches of less than
+        // one sample chunk (a one-sample pass over the 1080p frame: persistent 0.56 ms, single-wave workgroups 0.39, this 0.37)
+        if (w256 >= 16u) { want = 256u; pl.small_plain_grid = blob_bytes <= kSmallScene && !cold; }
+        else if (w512 >= 16u) want = 512u;
+        else if (w1024 >= 16u) want = 1024u;
+        else if (w256 >= w512 && w256 >= 8u) want = 256u;
+        else if (!cold && fits(1024u, 32u)) { want = 1024u; marker |= 32u; }      // F_NOSTASH: one LDS copy for 16 waves, lane state in registers
+        else want = w1024 ? 1024u : (w512 ? 512u : 256u);
+    }
+    if (force && in_lds) {
+        const u32 f = (u32)atoi(force);
+        if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; pl.small_plain_grid = false; } }
+    }
+    pk.features = (pk.features & 31u) | marker;
+    pl.in_lds = in_lds;
+    pl.block_threads = want;
+    pl.staged_bytes = blob_bytes;
+}
+
+}  // namespace
+
 static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
 {
     const u32 shard_count = opts->shard_count ? opts->shard_count : 1;
@@ -228,6 +343,8 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     std::string err;
     const int rc = pack_scene(desc, c->pk, err);
     if (rc != MRT_OK) { fail(rc, "mrt_create: %s", err.c_str()); delete c; return nullptr; }
+    Plan plan;
+    plan_launch(desc, c->pk, plan);          // may re-pack the scene (deep staging): before anything is uploaded
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -269,105 +386,10 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipMalloc((void **)&c->d_segments, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);   // + tile counter
     if ((e = hipMemset(c->d_segments, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
 
-    // ---- what is staged in LDS, and the launch shape -------------------------------------------------------------------
-    // LDS per workgroup = staged scene + lane stash (+ the mesh kernels' leaf queues): pt_lds_bytes knows.  Staging levels:
-    //   all     the whole packed scene (minus the octree leaf lists);
-    //   warm    F_COLD: membership tables and texels stay in global memory (touched at most once per shaded hit); the mesh
-    //           kernels spend the freed LDS on a per-lane leaf queue, so a mesh scene prefers this level when it fits;
-    //   deep    F_COLD | F_DEEP: meshes beyond the LDS.  The scene is packed again with the triangle-BVH table in level order
-    //           and as many of its first nodes -- the top levels of every tree -- as fit next to the small tables are staged;
-    //           deeper nodes and the triangles are read from global memory too;
-    //   none    everything through L2 (the small tables themselves do not fit).
-    // Launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
-    // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most:
-    //   256 threads (2x2 wave tiles of 8x8 pixels) + 10 KB lane stash per copy of the scene (64-thread workgroups -- one
-    //   wavefront, its own 5.5 KB of LDS -- served small scenes until round 3 and remain as a forced shape for the tests);
-    //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves.
-    // Environment (experiments, tests; read here, once): MRT_COLD=0/1 forbids / forces the warm level, MRT_DEEP_NODES=n forces
-    // the deep level with n staged nodes, MRT_SCENE_IN_L2 forces none, MRT_BLOCK_THREADS forces a workgroup size.
-    const bool no_lds = getenv("MRT_SCENE_IN_L2") != nullptr;
-    const char *force = getenv("MRT_BLOCK_THREADS");
-    const bool mesh_walk = c->pk.n_tbvh_nodes != 0u && (c->pk.features & 3u) == 3u;
-    auto lds_of = [&](u32 shape, u32 marker) { return pt_lds_bytes(c->pk.P, shape, true, (c->pk.features & 31u) | marker); };
-    auto fits = [&](u32 shape, u32 marker) { return lds_of(shape, marker) <= kLdsLimit; };
-    auto fits_any = [&](u32 marker) { return fits(256u, marker) || fits(512u, marker) || fits(1024u, marker); };
-    auto waves = [&](u32 shape, u32 marker) {            // resident wavefronts per CU of this shape, LDS-wise
-        const size_t l = lds_of(shape, marker);
-        return l > kLdsLimit ? (size_t)0 : (shape / 64u) * (kLdsLimit / (l ? l : 1));
-    };
-    constexpr u32 kWarm = 64u, kDeep = 64u | 128u;       // F_COLD, F_COLD | F_DEEP
-    const bool has_warm = c->pk.P.lds_words_warm < c->pk.P.lds_words;
-    u32 cold = 0u;
-    bool in_lds = !no_lds;
-    if (in_lds) {
-        const char *fc = getenv("MRT_COLD");
-        const char *fd = getenv("MRT_DEEP_NODES");
-        const bool warm_ok = has_warm && fits_any(kWarm) && !(fc && !atoi(fc));
-        const bool all_ok = fits_any(0u) && !(fc && atoi(fc) && warm_ok);
-        // a mesh scene takes the warm level when a 16-wave workgroup fits with stash and leaf queues (closest-hit walks in one
-        // round: VALU -8.5 %, time -2 % on the 967-triangle bench scene); everything else takes the whole scene when it fits;
-        // an instance-BVH scene whose texels alone force a single 1024-thread workgroup per CU takes the warm level too: its
-        // kernel is built for 6 waves per SIMD, which 256-thread workgroups around an LDS copy without the texels can supply
-        const bool bvh_no_mesh = (c->pk.features & 16u) != 0u && (c->pk.features & 2u) == 0u;
-        if (fd && mesh_walk) cold = kDeep;
-        else if (mesh_walk && warm_ok && fits(1024u, kWarm)) cold = kWarm;
-        else if (bvh_no_mesh && warm_ok && !fc && waves(256u, 0u) < 16u && waves(256u, kWarm) >= 24u) cold = kWarm;
-        else if (all_ok) cold = 0u;
-        else if (warm_ok) cold = kWarm;
-        else if (mesh_walk) cold = kDeep;
-        else in_lds = false;
-        if (cold == kDeep) {
-            const size_t stash1024 = (size_t)ST_SLOTS * 1024u * sizeof(float);               // lane stash of one 1024-thread workgroup
-            PackOpts po; po.tbvh_level_order = true;
-            Packed again; std::string err2;
-            bool ok2 = pack_scene(desc, again, err2, po) == MRT_OK && again.tbvh_level_order;
-            const size_t front = ok2 ? (size_t)again.P.off_tbvh * 4 : 0;                         // everything hot in front of the node table
-            ok2 = ok2 && front + stash1024 + 1024 < kLdsLimit;
-            if (ok2) {
-                const size_t room = (kLdsLimit - stash1024 - 1024 - front) / (BVH_WORDS * 4);
-                size_t n = fd ? (size_t)strtoul(fd, nullptr, 10) : room;
-                if (n > room) n = room;
-                if (n > again.n_tbvh_nodes) n = again.n_tbvh_nodes;
-                const u32 n_mesh = (again.P.off_node - again.P.off_mesh) / MESH_WORDS;
-                ok2 = n >= n_mesh && n_mesh > 0u;            // every root is staged (the walk reads it from LDS unconditionally)
-                if (ok2) {
-                    const u32 keep = c->pk.features;
-                    c->pk = again;
-                    c->pk.features = keep;
-                    c->pk.P.n_tbvh_hot = (u32)n;
-                    c->pk.P.lds_words_hot = (c->pk.P.off_tbvh + (u32)n * BVH_WORDS + 3u) & ~3u;
-                    // the blob on the device is the one packed first: replace it
-                    (void)hipFree(c->d_blob); c->d_blob = nullptr;
-                    const size_t bytes2 = (size_t)c->pk.blob.size() * 4;
-                    if ((e = hipMalloc((void **)&c->d_blob, bytes2)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(scene)", e);
-                    if ((e = hipMemcpy(c->d_blob, c->pk.blob.data(), bytes2, hipMemcpyHostToDevice)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemcpy(scene)", e);
-                }
-            }
-            if (!ok2) { cold = 0u; in_lds = false; }
-        }
-    }
-    c->scene_in_lds = in_lds;
-    const size_t full_bytes = (size_t)c->pk.P.lds_words * 4;
-    const size_t blob_bytes = in_lds ? (size_t)staged_words_for(c->pk.P, cold) * 4 : full_bytes;
-    u32 want = 256u, marker = cold;
-    if (in_lds) {
-        const size_t w256 = waves(256u, cold), w512 = waves(512u, cold), w1024 = waves(1024u, cold);
-        // small scenes (<= 6 KB: ~29 single-wave workgroups per CU would fit): 256-thread workgroups all the same -- four waves
-        // around one LDS copy, so that 32 waves per CU fit: +4 % on the headline frame, +7 % with the 8-wave build of the plane /
-        // sphere kernel, +4 % on CornellBox2 -- persistent for batched launches, on the plain grid for launches of less than
-        // one sample chunk (a one-sample pass over the 1080p frame: persistent 0.56 ms, single-wave workgroups 0.39, this 0.37)
-        if (w256 >= 16u) { want = 256u; c->small_plain_grid = blob_bytes <= kSmallScene && !cold; }
-        else if (w512 >= 16u) want = 512u;
-        else if (w1024 >= 16u) want = 1024u;
-        else if (w256 >= w512 && w256 >= 8u) want = 256u;
-        else if (!cold && fits(1024u, 32u)) { want = 1024u; marker |= 32u; }      // F_NOSTASH: one LDS copy for 16 waves, lane state in registers
-        else want = w1024 ? 1024u : (w512 ? 512u : 256u);
-    }
-    if (force && in_lds) {
-        const u32 f = (u32)atoi(force);
-        if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; c->small_plain_grid = false; } }
-    }
-    c->pk.features = (c->pk.features & 31u) | marker;
+    c->scene_in_lds = plan.in_lds;
+    c->small_plain_grid = plan.small_plain_grid;
+    const u32 want = plan.block_threads;
+    const size_t blob_bytes = plan.staged_bytes;
     c->block_threads = want;
     c->pk.P.tiles_x = want == 64u ? 1u : (want == 256u ? 2u : 4u);
     c->pk.P.tiles_y = want == 64u ? 1u : (want == 1024u ? 4u : 2u);
@@ -950,6 +972,30 @@ int mrt_get_stats(mrt_ctx *c, mrt_stats *out)
     if (c->pending) { int rc = set_device(c); if (rc) return rc; if ((rc = settle(c))) return rc; }      // an observation: booked samples are traced first
     if (c->stats_pending) { const int rc = resolve_stats(c); if (rc) return rc; }
     *out = c->stats;
+    ok();
+    return MRT_OK;
+}
+
+int mrt_plan_launch(const mrt_render_desc *desc, mrt_plan *out)
+{
+    if (!desc || !out) return fail(MRT_ERR_ARG, "mrt_plan_launch: null argument");
+    Packed pk;
+    std::string err;
+    const int rc = pack_scene(desc, pk, err);
+    if (rc != MRT_OK) return fail(rc, "mrt_plan_launch: %s", err.c_str());
+    const u32 n_nodes = pk.n_tbvh_nodes;
+    Plan pl;
+    plan_launch(desc, pk, pl);
+    memset(out, 0, sizeof *out);
+    out->staging = !pl.in_lds ? 3u : ((pk.features & 128u) ? 2u : ((pk.features & 64u) ? 1u : 0u));
+    out->block_threads = pl.block_threads;
+    out->lds_bytes = (uint32_t)pt_lds_bytes(pk.P, pl.block_threads, pl.in_lds, pk.features);
+    out->staged_bytes = pl.in_lds ? (uint32_t)pl.staged_bytes : 0u;
+    out->scene_bytes = pk.P.lds_words * 4u;
+    out->kernel_features = pt_instantiation(pl.block_threads, pl.in_lds, pk.features);
+    out->tbvh_nodes = n_nodes;
+    out->tbvh_hot_nodes = !pl.in_lds ? 0u : ((pk.features & 128u) ? pk.P.n_tbvh_hot : n_nodes);
+    out->small_plain_grid = pl.small_plain_grid ? 1u : 0u;
     ok();
     return MRT_OK;
 }

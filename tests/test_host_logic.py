@@ -424,3 +424,53 @@ def test_level_ordered_triangle_bvh_walk_equals_the_depth_first_one(emu_mod):
             got, seg2 = emu_mod.render(h, 5, spp, deep_nodes=hot)
             assert seg2 == seg
             assert np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(ref).view(np.uint32)), hot
+
+
+def test_launch_plan_staging_levels_and_shapes(monkeypatch):
+    """The launch policy of csrc/mrt_api.cpp as data (mrt_plan_launch: host only): which part of the scene a workgroup stages
+    in LDS and the workgroup size, for the scenes of the BASELINE configs and the meshes beyond the LDS."""
+    from micro_raytracer_amd import _lib, load_render, scenes
+    LDS = 160 * 1024
+    plan = lambda d: _lib.plan_launch(load_render(d))
+    for k in ("MRT_COLD", "MRT_DEEP_NODES", "MRT_SCENE_IN_L2", "MRT_BLOCK_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    # small scenes: the whole scene, four waves around one copy, 8 workgroups per CU; one-sample launches on the plain grid
+    for d, feat in ((scenes.cornell_box(res=(1920, 1080)), 0), (scenes.cornell_box2(res=(1920, 1080)), 1), (scenes.default_scene(), 8)):
+        p = plan(d)
+        assert (p["staging"], p["block_threads"], p["kernel_features"], p["small_plain_grid"]) == ("all", 256, feat, 1), p
+        assert p["staged_bytes"] == p["scene_bytes"] < 6 * 1024 and 8 * p["lds_bytes"] <= LDS
+    # the 967-triangle mesh scene: warm (membership tables + texels out), one 1024-thread workgroup with stash and leaf queues
+    p = plan(scenes.mesh_scene())
+    assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("warm", 1024, 15 | 64), p
+    assert p["staged_bytes"] < p["scene_bytes"] and p["lds_bytes"] == p["staged_bytes"] + 1024 * 4 * (10 + 8) <= LDS
+    assert p["tbvh_hot_nodes"] == p["tbvh_nodes"] > 1000
+    # the Minecraft-shaped scene: warm, 256-thread workgroups (6-wave kernel: six of them per CU), texels out of LDS
+    p = plan(scenes.minecraft_like())
+    assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("warm", 256, 29 | 64), p
+    assert p["scene_bytes"] - p["staged_bytes"] > 70 * 1024 and 6 * p["lds_bytes"] <= LDS < 7 * p["lds_bytes"]
+    # meshes beyond the LDS: deep -- level-ordered triangle BVH, as many top nodes as fit, triangles out
+    for n in (5120, 20480):
+        p = plan(scenes.mesh_scene(res=(64, 36), n_tris=n))
+        assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("deep", 1024, 15 | 64 | 128), p
+        assert 3000 < p["tbvh_hot_nodes"] < p["tbvh_nodes"] and LDS - 4096 < p["lds_bytes"] <= LDS
+    # 1000 instances, no texels: nothing to leave out, one copy for a 1024-thread workgroup
+    p = plan(scenes.instance_grid())
+    assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("all", 1024, 8 | 16), p
+    # the knobs of the tests
+    monkeypatch.setenv("MRT_SCENE_IN_L2", "1")
+    p = plan(scenes.mesh_scene())
+    assert (p["staging"], p["block_threads"], p["staged_bytes"], p["tbvh_hot_nodes"]) == ("none", 256, 0, 0), p
+    monkeypatch.delenv("MRT_SCENE_IN_L2")
+    monkeypatch.setenv("MRT_COLD", "0")
+    p = plan(scenes.minecraft_like())
+    assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("all", 1024, 29), p
+    p = plan(scenes.mesh_scene())
+    assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("all", 1024, 15), p
+    monkeypatch.delenv("MRT_COLD")
+    monkeypatch.setenv("MRT_DEEP_NODES", "5")
+    p = plan(scenes.mesh_scene(res=(64, 36), n_tris=300))
+    assert (p["staging"], p["tbvh_hot_nodes"], p["kernel_features"] & 192) == ("deep", 5, 192), p
+    monkeypatch.delenv("MRT_DEEP_NODES")
+    monkeypatch.setenv("MRT_BLOCK_THREADS", "64")
+    p = plan(scenes.cornell_box())
+    assert (p["block_threads"], p["small_plain_grid"]) == (64, 0), p
