@@ -383,8 +383,8 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if ((e = hipMalloc((void **)&c->d_accum_own, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc(accumulator)", e);
     c->d_accum = c->d_accum_own;
     if ((e = hipMemset(c->d_accum, 0, acc_bytes)) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
-    if ((e = hipMalloc((void **)&c->d_segments, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);   // + tile counter
-    if ((e = hipMemset(c->d_segments, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
+    if ((e = hipMalloc((void **)&c->d_segments, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMalloc", e);   // + tile counter + 4 phase clocks (debug builds)
+    if ((e = hipMemset(c->d_segments, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(MRT_ERR_DEVICE, "hipMemset", e);
 
     c->scene_in_lds = plan.in_lds;
     c->small_plain_grid = plan.small_plain_grid;
@@ -521,6 +521,15 @@ static int resolve_stats(mrt_ctx *c)
         HIP_TRY(hipMemcpy(&seg, c->d_segments, sizeof seg, hipMemcpyDeviceToHost));
         c->stats.segments = seg;
     }
+#ifdef MRT_PHASE_TIMING
+    {   // debug build: shader-clock ticks per phase, summed over wavefronts since the context was created
+        unsigned long long t[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(t, c->d_segments + 2, sizeof t, hipMemcpyDeviceToHost));
+        const double tot = (double)(t[0] + t[1] + t[2] + t[3]);
+        fprintf(stderr, "[mrt phase ticks] closest-hit query %.3f  shading %.3f  shadow query %.3f  ray set-up / regeneration %.3f  (total %.4g wave-ticks)\n",
+                t[0] / tot, t[1] / tot, t[2] / tot, t[3] / tot, tot);
+    }
+#endif
     return MRT_OK;
 }
 

@@ -92,6 +92,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT, BLOCK_THREADS))
     if constexpr (leaf_queue_for(FEAT) != 0u)
         S.lq = (void *)(reinterpret_cast<float *>(lds_blob + stash_base4) + (kStash ? stash_slots_for(FEAT, BLOCK_THREADS) * BLOCK_THREADS : 0u) + threadIdx.x);
     u32 segments = 0;
+#ifdef MRT_PHASE_TIMING
+    unsigned long long wave_ticks[4] = {0ull, 0ull, 0ull, 0ull};
+#endif
     // one 8x8 tile of shard-local rows for this wavefront, lane k of the sample split
     auto do_tile = [&](u32 tx, u32 ty, u32 k) {
         const u32 x = tx * 8u + (lane & 7u);
@@ -107,9 +110,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT, BLOCK_THREADS))
         job.word = (ry * P.nw + x) * 3u;        // < 2^32: mrt_create limits a shard to 2^30 pixels
         if constexpr (lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS, FEAT)) {
             // per-lane column behind the scene blob (16-byte aligned): ST_SLOTS x blockDim floats
+#ifdef MRT_PHASE_TIMING
+            unsigned long long tk[4] = {0ull, 0ull, 0ull, 0ull};
+#else
+            unsigned long long *tk = nullptr;
+#endif
             LdsStash<BLOCK_THREADS> st;
             st.base = (lds_vfloat *)(reinterpret_cast<float *>(lds_blob + stash_base4) + threadIdx.x);
-            render_pixel<FEAT>(S, st, x, y, job, seg);
+            render_pixel<FEAT>(S, st, x, y, job, seg, tk);
+#ifdef MRT_PHASE_TIMING
+            for (int k = 0; k < 4; ++k) wave_ticks[k] += tk[k];
+#endif
         } else {
             RegStash st;
             render_pixel<FEAT>(S, st, x, y, job, seg);
@@ -137,6 +148,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT, BLOCK_THREADS))
         do_tile(tx, ty, k);
         if (!persist) break;
     }
+#ifdef MRT_PHASE_TIMING
+    // one lane per wavefront (the longest-running one speaks for the wave: every lane carries the wave's clock differences)
+    for (int k = 0; k < 4; ++k) {
+        unsigned long long v = wave_ticks[k];
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+        if (lane == 0 && v) atomicAdd(P.segments + 2 + k, v);
+    }
+#endif
     if (P.count_segments) {
         // wave-level sum (every lane of the wavefront is here), one atomic per wavefront
         u32 v = segments;

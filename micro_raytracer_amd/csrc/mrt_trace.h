@@ -48,6 +48,17 @@ constexpr u32 leaf_queue_for(u32 feat) { return ((feat & F_COLD) && !(feat & F_D
 #ifndef MRT_PROBE_INST                 // flat instance index about to be tested (tests/emu/probe2.cpp)
 #define MRT_PROBE_INST(i)
 #endif
+// Phase timing (debug builds with -DMRT_PHASE_TIMING only: profiles/README.md): shader-clock ticks a wavefront spends between
+// the marks of the main loop, summed per phase; the marks sit where every live lane of the wavefront passes.
+#if defined(MRT_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define MRT_TICK(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); phase_ticks[slot] += now_ - phase_last; phase_last = now_; } while (0)
+#define MRT_TICK_DECL unsigned long long phase_ticks[4] = {0ull, 0ull, 0ull, 0ull}; unsigned long long phase_last = __builtin_amdgcn_s_memtime()
+#define MRT_TICK_OUT(dst) do { for (int k_ = 0; k_ < 4; ++k_) (dst)[k_] = phase_ticks[k_]; } while (0)
+#else
+#define MRT_TICK(slot)
+#define MRT_TICK_DECL
+#define MRT_TICK_OUT(dst)
+#endif
 #ifndef MRT_PROBE_ROUND                // one round of a lane's triangle-BVH walk: box steps taken, triangles tested, membership boxes
 #define MRT_PROBE_ROUND(steps, tris, membs)
 #endif
@@ -974,8 +985,9 @@ struct LaneJob {
 // (src/sampler.rs:45-70 calling RayTracer::iter / reduce_light, src/rt.rs:937-994, whose iterator
 // is RaytraceIterator::next, src/rt.rs:1014-1066).
 template <u32 FEAT, class Stash>
-MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &job, u32 &segments)
+MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &job, u32 &segments, unsigned long long *ticks = nullptr)
 {
+    MRT_TICK_DECL;
     const Params &P = *S.P;
     const u32 pixel = y * P.nw + x;
     const u32 pix_key = mix32(pixel + P.seed_lo) ^ P.seed_hi;      // path_key = mix32(pix_key + sample * kGold)
@@ -1031,7 +1043,10 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
         bool ended = false;
         V3 X = v3(0.0f, 1.0f, 0.0f);             // un-normalised direction of the next ray
         V3 base = o;                             // the point it leaves from (hit point, or lens position)
-        if (!trace<false, FEAT>(S, ray, h)) {
+        MRT_TICK(3);                                                   // loop bottom -> here: ray set-up
+        const bool hit_any = trace<false, FEAT>(S, ray, h);
+        MRT_TICK(0);                                                   // the closest-hit query
+        if (!hit_any) {
             // primary miss: raw sky colour (src/rt.rs:957-959); otherwise the fold starts from sky*pwr (:964)
             contrib = (b == 0) ? v3(P.sky[0], P.sky[1], P.sky[2]) : add(getL(), hadam(getT(), sky_init));
             ended = true;
@@ -1114,7 +1129,10 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                         const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
                         const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
                         Hit hs;
-                        if (trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs)) continue;
+                        MRT_TICK(1);                                   // shading up to the shadow query (lanes that ask one)
+                        const bool blocked = trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs);
+                        MRT_TICK(2);                                   // the shadow query
+                        if (blocked) continue;
                         l_col = add(l_col, term);
                     }
                     // the fold step (d_col + l_col) * pwr, src/rt.rs:990-992, front to back
@@ -1130,6 +1148,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
             }
         }
     
+        MRT_TICK(1);                                                   // shading (rest)
         bool from_camera = false;
         if (ended) {
             csum = add(csum, contrib);
@@ -1173,6 +1192,8 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
         q[0] = acc.x; q[1] = acc.y; q[2] = acc.z;
     }
     segments = seg;
+    (void)ticks;
+    MRT_TICK_OUT(ticks);
 }
 
 }  // namespace mrt
