@@ -870,13 +870,15 @@ MRT_HD V3 surf_color(const Scn &S, const Surf &s)
     return albedo;
 }
 
-// RayTracer::rand, src/rt.rs:996-1007
+// RayTracer::rand, src/rt.rs:996-1007.  Math contract v3: cos th = 1 - 2 u1 and sin th = sqrt(4 u1 (1 - u1)) directly instead
+// of sin / cos of acos(1 - 2 u1) (both factors exact, one rounding, one correctly rounded root: see oracle/mrt_oracle.c
+// rt_rand and DESIGN.md section 4) -- an acos and a sincos less per scatter.
 MRT_HD V3 rand_normal(V3 n, float r, float u1, float u2)
 {
-    const float th = acos_(1.0f - 2.0f * u1);
     const float phi = u2 * 2.0f * kPi;
-    float sth, cth, sphi, cphi;
-    sincos_(th, sth, cth);
+    const float cth = 1.0f - 2.0f * u1;
+    const float sth = sqrt_((4.0f * u1) * (1.0f - u1));
+    float sphi, cphi;
     sincos_(phi, sphi, cphi);
     const V3 v = v3(sth * cphi, sth * sphi, cth);
     return norm(add(n, muls(v, r)));

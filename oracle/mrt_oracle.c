@@ -598,13 +598,16 @@ static ray_t camera_ray(const orc_ctx *c, const pixel_cam_t *pc, uint32_t pk)
     return ray_cast_default(pos, m3_mul(&rot_y, t));
 }
 
-/* RayTracer::rand, src/rt.rs:996-1007 */
+/* RayTracer::rand, src/rt.rs:996-1007.  Math contract v3: the reference takes th = acos(1 - 2 u1) and then
+ * sin th, cos th through libm; here cos th = 1 - 2 u1 (exact: u1 lies on the 2^-23 lattice) and sin th = sqrt(4 u1 (1 - u1))
+ * = sqrt((1 - cos th)(1 + cos th)) with both factors exact, one rounding in the product and a correctly rounded root: the same
+ * two numbers to within an ulp (the libm composition is off by up to ~1e-7 near the poles, where acos loses the angle). */
 static v3 rt_rand(v3 n, float r, float u1, float u2)
 {
-    float th = om_acosf(1.0f - 2.0f * u1);
     float phi = u2 * 2.0f * OM_PI;
-    float sth, cth, sphi, cphi;
-    om_sincosf(th, &sth, &cth);
+    float cth = 1.0f - 2.0f * u1;
+    float sth = sqrtf((4.0f * u1) * (1.0f - u1));
+    float sphi, cphi;
     om_sincosf(phi, &sphi, &cphi);
     v3 v = V3(sth * cphi, sth * sphi, cth);
     return v3_norm(v3_add(n, v3_muls(v, r)));
