@@ -53,6 +53,11 @@ constexpr int waves_for(u32 feat, int block_threads)
     // wait on dependent LDS reads, not on issue slots: the Minecraft-shaped scene gains 12 % with 5 waves, 16 % with 6, 17 %
     // with 7-8 over the 4 its 114 VGPRs allow.  The mesh kernels stay at 4: their LDS footprint caps them at 16 waves per CU.
     if ((feat & F_COLD) && (feat & F_BVH) && !(feat & F_TRI)) return MRT_BVH_WAVES;
+    // Scenes with lights but without meshes, triangles or an instance BVH (example/Default.json, dof.json: 106-122 VGPRs as the
+    // compiler would have it, 4 waves): bound to 5 waves per SIMD (96 VGPRs).  1080p renders: default scene 110 -> 118
+    // Gsamples/s, dof scene 17.7 -> 20.3 (6 waves: 111 / 19.2).  The mesh kernels lose with every register taken from them
+    // (kitchen-sink scene: 3284 / 3095 / 2765 Msamples/s at 4 / 5 / 6 waves).
+    if ((feat & F_LIGHTS) && !(feat & (F_TRI | F_BVH | F_COLD | F_NOSTASH)) && block_threads <= 256) return 5;      // (larger workgroups: LDS-capped at 16 waves per CU anyway)
     return (feat & ~F_BOX) == 0 ? 7 : ((feat & (F_LIGHTS | F_TRI | F_BVH)) == 0 ? 6 : 4);      // the BVH walks need their registers more than two extra waves
 #endif
 }
