@@ -52,8 +52,12 @@ def _worker(rank, world, port, out_path, no_gather=False):
             full[b0:b0 + 8] = a[b0:b0 + 8]
     local = torch.zeros((padded_rows(nh, world), nw, 3), dtype=torch.float32)
     local[: len(rows)] = torch.from_numpy(full[rows])
-    frame = gather_frame(local, nh, nw, dst=0, use_all_gather=use_all_gather)
+    # receive buffers allocated once and reused (ShardedSampler does this): a first exchange of other contents, then the real one
+    parts = [torch.empty_like(local) for _ in range(world)] if (rank == 0 or use_all_gather) else None
+    gather_frame(torch.full_like(local, 7.0), nh, nw, dst=0, use_all_gather=use_all_gather, parts=parts)
+    frame = gather_frame(local, nh, nw, dst=0, use_all_gather=use_all_gather, parts=parts)
     if rank == 0:
+        assert all(p.data_ptr() == q.data_ptr() for p, q in zip(parts, parts))      # still the caller's buffers
         np.save(out_path, frame.numpy())
     dist.barrier()
     dist.destroy_process_group()
