@@ -109,7 +109,12 @@ def _rows_on(device, nh, rank, world, shard_rows):
 
 class ShardedSampler:
     """Sampler for rank `rank` of `world` GPUs: execute() renders this rank's rows and gathers the frame
-    on rank 0; img() is served by rank 0 (Sampler::img needs every row)."""
+    on rank 0; img() is served by rank 0 (Sampler::img needs every row).
+
+    The render description is fixed at construction: a shard's rows live in a tensor bound to the library and its sample
+    count cannot be restored into a rebuilt context, so editing `self.render` in place once samples are on board makes the
+    next execute() raise MrtError (MRT_ERR_STATE) instead of silently rendering into fresh memory; build a new
+    ShardedSampler for another scene."""
 
     def __init__(self, render, rank: int, world: int, device: int, seed: int = 1, shard_rows: int = DEFAULT_SHARD_ROWS, flags: int = 0):
         import torch
