@@ -69,7 +69,7 @@ def cpu_baseline(render, seconds_target=12.0):
     The thread count is measured, not assumed: a container may show 256 CPUs in its affinity mask and be throttled to a
     16-CPU share, where 256 threads meeting at a barrier per pass waste most of their slices.  A short probe on a row
     band picks the fastest of a few pool sizes; a single-thread run of the same band gives the per-core reference
-    figure, so the line carries `per_core` next to `single_thread` (they should agree within ~2x)."""
+    figure, so the line carries `per_thread` next to `single_thread` (they should agree within ~2x)."""
     from micro_raytracer_amd import _abi
     from oracle import oracle
     aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -90,10 +90,12 @@ def cpu_baseline(render, seconds_target=12.0):
         o.execute(1, threads=t, rows=band)                  # thread creation
         dt = o.execute(n, threads=t, rows=band)
         probes[t] = round(band_px * n / dt / 1e6, 4)
-    # the smallest pool within 15 % of the fastest: past the container's CPU share more threads only add SMT siblings
-    # and time slicing (first run on the GPU box: 16 threads 5.70, 32 threads 6.37, 256 threads 4.88 Msamples/s)
+    # `value` is measured with the FASTEST probed pool (the baseline must not be understated); the smallest pool within 15 %
+    # of it is reported next to it for information: past the container's CPU share more threads only add SMT siblings and
+    # time slicing (GPU box: 16 threads 5.70, 32 threads 6.37, 256 threads 4.88 Msamples/s on the probe band)
     top = max(probes.values())
-    best_t = min(t for t, r in probes.items() if r >= 0.85 * top)
+    best_t = max(probes, key=lambda t: (probes[t], -t))
+    lean_t = min(t for t, r in probes.items() if r >= 0.85 * top)
     best_rate = probes[best_t]
     # the measurement: full-frame passes (n_dim = 64 -> 4096 jobs, join per pass) with the best pool, ~seconds_target
     o.reset()
@@ -103,9 +105,23 @@ def cpu_baseline(render, seconds_target=12.0):
     o.close()
     value = frame_px * spp / dt / 1e6
     return {"value": value, "unit": "Msamples/s", "cores": best_t, "threads": best_t, "affinity_cpus": aff, "kind": "port",
-            "per_core": value / best_t, "single_thread": single, "pool_probe_Msamples_s": probes,
+            "per_thread": value / best_t, "single_thread": single, "pool_probe_Msamples_s": probes,
+            "smallest_pool_within_15pct": lean_t,
             "sample": f"{spp} full-frame pass(es) of the {nw}x{nh} frame (n_dim 64: 4096 tile jobs, join per pass), {dt:.1f} s, "
-                      f"{best_t} threads (smallest probed pool within 15 % of the fastest; {aff} CPUs in the affinity mask)"}
+                      f"{best_t} threads (the fastest probed pool; {aff} CPUs in the affinity mask)"}
+
+
+def check_ranks(backend, pg_world, everyone):
+    """The `dist` block of a multi-rank bench line, from what every rank reported about itself (all_gather_object).
+    Under RCCL ("nccl") every rank must sit on a device of its own: two ranks on one device is a rehearsal layout
+    (MRT_SHARE_DEVICE=1 with gloo), not a scaling measurement -- refused with a non-zero exit."""
+    ranks = sorted(everyone, key=lambda r: r["rank"])
+    if [r["rank"] for r in ranks] != list(range(pg_world)):
+        raise SystemExit(f"process group of {pg_world} rank(s) reported ranks {[r['rank'] for r in ranks]}")
+    ident = [(r.get("device_uuid") or r.get("pci_bus_id") or "", r["device_index"]) for r in ranks]
+    if backend == "nccl" and len(set(ident)) != pg_world:
+        raise SystemExit(f"backend nccl with two ranks on one device: {ident}")
+    return {"backend": backend, "world_size": pg_world, "devices": ranks, "distinct_devices": len(set(ident))}
 
 
 VALU_ISSUE_PEAK_GINSTR = 1171.0   # G wave-instructions/s of independent v_mul/v_add/v_fma measured on MI355X (DESIGN.md §7)
@@ -128,6 +144,35 @@ def pmc_profile(workload, world):
 
 
 PMC_STALE_TOLERANCE = 0.03
+
+
+def roofline_block(replay, valu_tflops, hbm_achieved, alg_bytes, alg_bytes_8d, kernel_name, k_ms, k_min, k_max, gather_ms, reduce_ms):
+    """`roofline` of the dominant kernel.  The bound that binds is FP32 VALU issue (neither HBM nor MFMA --
+    the scene lives in LDS and there is no dense contraction), so `bound` says so and `frac` is
+      * with a fresh PMC profile of this very kernel (pmc_replay): the share of the architectural VALU issue rate spent on
+        ACTIVE lanes = valu_issue_frac x lane_utilisation (achieved / peak in G wave-instructions/s, lane-weighted);
+      * otherwise the section-8d flop model: segments x 400 flop / kernel time against the 157.3 TFLOP/s vector peak.
+    The HBM view BASELINE.json asks for stays as the `hbm` sub-block (by construction << 1 %)."""
+    hbm = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_8d": alg_bytes_8d,
+           "traffic": replay["traffic"], "traffic_source": replay["traffic_source"],
+           "note": "by construction not HBM-bound (SURVEY.md section 8d): HBM sees 24 B per pixel per launch, or with the sample split one 12 B "
+                   "chunk sum per pixel per 16 samples, which reduce_chunks (reduce_ms) folds into the accumulator"}
+    model_frac = valu_tflops / VALU_PEAK_TFLOPS
+    if replay["valu_issue_frac"] is not None and replay["lane_utilisation"] is not None:
+        g = replay["valu_issue_frac"] * VALU_ISSUE_ARCH_GINSTR
+        top = {"bound": "valu_issue", "achieved": g * replay["lane_utilisation"], "peak": VALU_ISSUE_ARCH_GINSTR,
+               "unit": "G wave-instr/s (active-lane weighted)", "frac": replay["valu_issue_frac"] * replay["lane_utilisation"],
+               "frac_source": "pmc"}
+    else:
+        top = {"bound": "valu_issue", "achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": model_frac,
+               "frac_source": "flop_model"}
+    top.update({"traffic": replay["traffic"], "valu_model_frac": model_frac, "valu_issue_frac": replay["valu_issue_frac"],
+                "lane_utilisation": replay["lane_utilisation"], "pmc_stale": replay["pmc_stale"], "kernel": kernel_name,
+                "kernel_ms": k_ms, "kernel_ms_rank_min": k_min, "kernel_ms_rank_max": k_max, "gather_ms": gather_ms,
+                "reduce_ms": reduce_ms, "hbm": hbm,
+                "note": "kernel_ms is pt_megakernel alone (HIP events on the launch stream)"})
+    return top
 
 
 def pmc_replay(workload, world, kernel_name, kernel_ms, spp_overridden):
@@ -209,6 +254,21 @@ def main():
                 dist.init_process_group(backend="nccl")
         else:
             dist.init_process_group(backend=backend)
+
+    # What the process group really is (world > 1): backend, world size as the GROUP reports it, the device of every rank.
+    # A launcher that started fewer ranks than --gpus, or two RCCL ranks on one device, must not produce a bench line.
+    dist_info = None
+    if world > 1:
+        pg_world = dist.get_world_size()
+        if pg_world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {pg_world} rank(s)")
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": local_rank,
+                "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "device_name": props.name}
+        everyone = [None] * pg_world
+        dist.all_gather_object(everyone, mine)
+        dist_info = check_ranks(dist.get_backend(), pg_world, everyone)      # raises SystemExit on a bad layout
 
     from micro_raytracer_amd.dist import ShardedSampler
 
@@ -313,15 +373,8 @@ def main():
                        "bounce": render.rt.bounce, "samples_per_step": float(nw) * nh * spp,
                        "calls_per_step": spp if percall else 1,
                        "sharding": f"rows, block-cyclic x{ss.shard_rows}, {world} rank(s), 1 RCCL gather/step" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         # the bound that binds (neither HBM nor MFMA): FP32 VALU issue and lane utilisation
-                         "algorithmic_bytes_8d": alg_bytes_8d, "valu_model_frac": valu_tflops / VALU_PEAK_TFLOPS,
-                         "valu_issue_frac": replay["valu_issue_frac"], "lane_utilisation": replay["lane_utilisation"],
-                         "traffic": replay["traffic"], "traffic_source": replay["traffic_source"], "pmc_stale": replay["pmc_stale"],
-                         "kernel": kernel_name, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_ms_rank_min": k_min, "kernel_ms_rank_max": k_max,
-                         "gather_ms": sum(gather_ms) / max(1, len(gather_ms)) if world > 1 else 0.0,
-                         "note": "by construction not HBM-bound (SURVEY.md §8d): the scene lives in LDS, HBM sees 24 B per pixel per launch, or with sample split one 12 B chunk sum per pixel per 16 samples, which reduce_chunks (reduce_ms) then folds into the accumulator; kernel_ms is pt_megakernel alone", "reduce_ms": st.get("reduce_ms")},
+            "roofline": roofline_block(replay, valu_tflops, achieved, alg_bytes, alg_bytes_8d, kernel_name, k_ms, k_min, k_max,
+                                       sum(gather_ms) / max(1, len(gather_ms)) if world > 1 else 0.0, st.get("reduce_ms")),
             "valu": {"achieved_tflops": valu_tflops, "peak_tflops": VALU_PEAK_TFLOPS, "frac": valu_tflops / VALU_PEAK_TFLOPS,
                      "segments_per_sample": total_segments / samples, "flop_per_segment_model": FLOP_PER_SEGMENT,
                      "Gsegments_per_s": total_segments / elapsed / 1e9},
@@ -338,6 +391,11 @@ def main():
             line["valu"]["pmc"] = replay["valu_pmc"]
         if replay["pmc_stale"]:
             line["roofline"]["pmc_stale_why"] = replay["pmc_stale_why"]
+        if dist_info is not None:
+            pr = ss.s.padded_rows()
+            dist_info.update(gather_bytes_per_rank=pr * nw * 12, use_all_gather=bool(ss.use_all_gather), shard_rows=ss.shard_rows,
+                             exchange="one gather of the padded shard accumulators to rank 0 per step (reference src/sampler.rs:60-70)")
+            line["dist"] = dist_info
         if deferred:
             line["config"]["deferred_active"] = bool(st.get("deferred"))
         if world == 1 and not args.no_cpu_baseline:

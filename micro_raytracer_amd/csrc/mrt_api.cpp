@@ -104,15 +104,21 @@ bool env_on(const char *name)
     return v && *v && strtol(v, nullptr, 10) != 0;
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for every instantiation: once per device, not per mrt_create
-constexpr int kMaxDevices = 64;
-std::once_flag g_cfg_once[kMaxDevices];
-hipError_t g_cfg_result[kMaxDevices];
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for every instantiation: once per device, not per mrt_create.  A device counts
+// as configured only after a SUCCESSFUL pass, so a transient failure is retried by the next mrt_create instead of being
+// returned for the rest of the process; the table grows with the device index.
+std::mutex g_cfg_mu;
+std::vector<char> g_cfg_done;
 hipError_t configure_pt_once(int device)      // the caller has made `device` current
 {
-    if (device < 0 || device >= kMaxDevices) return configure_pt(kLdsLimit);
-    std::call_once(g_cfg_once[device], [device]() { g_cfg_result[device] = configure_pt(kLdsLimit); });
-    return g_cfg_result[device];
+    if (device < 0) return configure_pt(kLdsLimit);
+    std::lock_guard<std::mutex> lock(g_cfg_mu);
+    if ((size_t)device < g_cfg_done.size() && g_cfg_done[device]) return hipSuccess;
+    const hipError_t e = configure_pt(kLdsLimit);
+    if (e != hipSuccess) return e;
+    if ((size_t)device >= g_cfg_done.size()) g_cfg_done.resize((size_t)device + 1, 0);
+    g_cfg_done[device] = 1;
+    return hipSuccess;
 }
 
 }  // namespace
@@ -681,6 +687,10 @@ static int exec_group(mrt_ctx *g, uint32_t n_samples)
         g->stats.samples += s->stats.samples; g->stats.segments += s->stats.segments; g->stats.launches += s->stats.launches;
         float ms = 0;
         HIP_TRY(hipSetDevice(s->device));
+        // a sub-context without rows of its own (a frame of fewer row blocks than devices) or a call with n_samples == 0
+        // still joined the gather, but exec_finish did not synchronise its stream: wait for its closing event here, or
+        // hipEventElapsedTime answers hipErrorNotReady after the counts have been advanced
+        HIP_TRY(hipEventSynchronize(s->ev_g1));
         HIP_TRY(hipEventElapsedTime(&ms, s->ev_g0, s->ev_g1));
         if (ms > gather_ms) gather_ms = ms;
     }
@@ -897,24 +907,41 @@ static int img_prepare(mrt_ctx *c)
     if (rw == nw && rh == nh) return MRT_OK;
     if (rw == 0 || rh == 0) return fail(MRT_ERR_SCENE, "mrt_img: zero output resolution");
     if (!c->d_out) {
+        // everything is allocated and filled through locals and committed to the context only when all of it succeeded: a
+        // failure half-way leaves the context as it was (d_out still null), so the next mrt_img starts over instead of
+        // allocating over live pointers
         ResampleTaps v, h;
         lanczos3_taps(nh, rh, v);
         lanczos3_taps(nw, rw, h);
+        u32 *vl = nullptr, *vc = nullptr, *hl = nullptr, *hc = nullptr;
+        float *vw = nullptr, *hw = nullptr, *tmp = nullptr;
+        unsigned char *out = nullptr;
+        auto build = [&]() -> int {
+            HIP_TRY(hipMalloc((void **)&vl, sizeof(u32) * rh));
+            HIP_TRY(hipMalloc((void **)&vc, sizeof(u32) * rh));
+            HIP_TRY(hipMalloc((void **)&vw, sizeof(float) * (size_t)rh * v.cap));
+            HIP_TRY(hipMalloc((void **)&hl, sizeof(u32) * rw));
+            HIP_TRY(hipMalloc((void **)&hc, sizeof(u32) * rw));
+            HIP_TRY(hipMalloc((void **)&hw, sizeof(float) * (size_t)rw * h.cap));
+            HIP_TRY(hipMemcpy(vl, v.left.data(), sizeof(u32) * rh, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(vc, v.count.data(), sizeof(u32) * rh, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(vw, v.weight.data(), sizeof(float) * (size_t)rh * v.cap, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(hl, h.left.data(), sizeof(u32) * rw, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(hc, h.count.data(), sizeof(u32) * rw, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(hw, h.weight.data(), sizeof(float) * (size_t)rw * h.cap, hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void **)&tmp, sizeof(float) * (size_t)nw * rh * 3));
+            HIP_TRY(hipMalloc((void **)&out, (size_t)rw * rh * 3));
+            return MRT_OK;
+        };
+        const int rc = build();
+        if (rc) {
+            void *ptrs[] = {vl, vc, vw, hl, hc, hw, tmp, out};
+            for (void *q : ptrs) if (q) (void)hipFree(q);
+            (void)hipGetLastError();
+            return rc;
+        }
         c->vcap = v.cap; c->hcap = h.cap;
-        HIP_TRY(hipMalloc((void **)&c->d_vl, sizeof(u32) * rh));
-        HIP_TRY(hipMalloc((void **)&c->d_vc, sizeof(u32) * rh));
-        HIP_TRY(hipMalloc((void **)&c->d_vw, sizeof(float) * (size_t)rh * v.cap));
-        HIP_TRY(hipMalloc((void **)&c->d_hl, sizeof(u32) * rw));
-        HIP_TRY(hipMalloc((void **)&c->d_hc, sizeof(u32) * rw));
-        HIP_TRY(hipMalloc((void **)&c->d_hw, sizeof(float) * (size_t)rw * h.cap));
-        HIP_TRY(hipMemcpy(c->d_vl, v.left.data(), sizeof(u32) * rh, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_vc, v.count.data(), sizeof(u32) * rh, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_vw, v.weight.data(), sizeof(float) * (size_t)rh * v.cap, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_hl, h.left.data(), sizeof(u32) * rw, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_hc, h.count.data(), sizeof(u32) * rw, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_hw, h.weight.data(), sizeof(float) * (size_t)rw * h.cap, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)&c->d_tmp, sizeof(float) * (size_t)nw * rh * 3));
-        HIP_TRY(hipMalloc((void **)&c->d_out, (size_t)rw * rh * 3));
+        c->d_vl = vl; c->d_vc = vc; c->d_vw = vw; c->d_hl = hl; c->d_hc = hc; c->d_hw = hw; c->d_tmp = tmp; c->d_out = out;
     }
     return MRT_OK;
 }

@@ -503,8 +503,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
             mesh_tab.push_back(oc.root == NO_NODE ? NO_NODE : node0 + oc.root);
             mesh_tab.push_back(leaf0);
             mesh_tab.push_back(tb_ok ? tb0 : NO_NODE);
-            mesh_tab.push_back(tb_ok ? tb0 + (u32)(tbn.size() / BVH_WORDS) : 0u);        // MESH_TBVH_END
-            mesh_tab.push_back(0); mesh_tab.push_back(0);
+            mesh_tab.push_back(0); mesh_tab.push_back(0); mesh_tab.push_back(0);
             node_tab.insert(node_tab.end(), oc.nodes.begin(), oc.nodes.end());
             for (u32 id : oc.leaf_ids) leaf_tab.push_back(new_of[id]);
             for (u32 t = 0; t < o.n_tris; ++t) {
@@ -664,7 +663,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
             if (leaf_of(n) == 0u) q[BVH_LEAF] = fbits(BVH_INTERNAL | newi[n + 1]);
         }
         tbvh_tab.swap(re);
-        for (size_t k = 0; k + MESH_WORDS <= mesh_tab.size(); k += MESH_WORDS) if (mesh_tab[k + MESH_TBVH] != NO_NODE) { mesh_tab[k + MESH_TBVH] = newi[mesh_tab[k + MESH_TBVH]]; mesh_tab[k + MESH_TBVH_END] = 0u; }
+        for (size_t k = 0; k + MESH_WORDS <= mesh_tab.size(); k += MESH_WORDS) if (mesh_tab[k + MESH_TBVH] != NO_NODE) mesh_tab[k + MESH_TBVH] = newi[mesh_tab[k + MESH_TBVH]];
         out.tbvh_level_order = true;
     }
     P.off_mesh = B.align4(); B.w.insert(B.w.end(), mesh_tab.begin(), mesh_tab.end());

@@ -61,8 +61,8 @@ enum : u32 { TEX_W = 0, TEX_H = 1, TEX_OFF = 2, TEX_FMT = 3 };
 enum : u32 { TEXFMT_NONE = 0, TEXFMT_F32 = 1, TEXFMT_U8 = 2 };
 
 // MESH: [0] first triangle [1] triangle count [2] root node (0xffffffff: no octree) [3] leaf-id base
-//       [4] root node of the triangle BVH (0xffffffff: none)  [5] one past its last node (the mesh's nodes are contiguous)
-enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4, MESH_TBVH_END = 5 };
+//       [4] root node of the triangle BVH (0xffffffff: none)  [5..7] unused
+enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4 };
 constexpr u32 NO_NODE = 0xffffffffu;
 
 // NODE: [0..2] 0.5*aabb  [3..5] rel_pos  [6] first child node | first leaf id  [7] count | leaf<<31

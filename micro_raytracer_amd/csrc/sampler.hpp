@@ -38,7 +38,8 @@ public:
     double execute(const mrt_render_desc &render, uint32_t n_samples = 1)
     {
         const uint64_t print = fingerprint(render);
-        if (!ctx_ || print != print_) {
+        if (!ctx_ || print != print_ || stale_) {
+            stale_ = false;
             mrt_opts o{};
             o.abi_version = MRT_ABI_VERSION;
             o.seed = seed_;
@@ -93,6 +94,11 @@ public:
         return st;
     }
 
+    // The fingerprint hashes bulk data (triangles, texels) by address, length and a strided sample of its words: an edit IN
+    // PLACE that falls between the sample points is not seen.  A caller that edits bulk arrays in place says so here; the
+    // next execute() rebuilds the context from the description it is given (sums carried over as for any other change).
+    void invalidate() { stale_ = true; }
+
     uint32_t width() const { return res_w_; }
     uint32_t height() const { return res_h_; }
     uint32_t contexts_created() const { return created_; }
@@ -134,6 +140,7 @@ private:
     uint64_t print_ = 0;
     uint32_t nw_ = 0, nh_ = 0, res_w_ = 0, res_h_ = 0;
     uint32_t created_ = 0;
+    bool stale_ = false;
 };
 
 // CLI::raytrace / HttpServer::raytrace, src/cli.rs:155-177, src/http.rs:136-148

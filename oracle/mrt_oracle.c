@@ -3,8 +3,8 @@
  * See mrt_oracle.h for the rules about who may use this and for the parity-pin status.
  *
  * Every function cites the reference lines it restates (paths relative to the reference
- * checkout).  f32 arithmetic follows the reference's operation order exactly; compile with
- * -ffp-contract=off.  Deliberate, documented differences from the Rust binary:
+ * checkout).  f32 arithmetic follows the reference's operation order (the one exception is D8);
+ * compile with -ffp-contract=off.  Deliberate, documented differences from the Rust binary:
  *   D1  RNG: seeded counter RNG instead of rand::thread_rng (unseedable).
  *   D2  sin/cos/acos/atan2/powf: the math contract of oracle_math.h instead of libm.
  *   D3  reduce_light evaluates the path once (the reference traces it twice, src/rt.rs:957-961;
@@ -14,6 +14,12 @@
  *   D6  Pixels of the over-covering tiles beyond nw x nh (src/sampler.rs:32-33,45-48) are not
  *       computed: Sampler::img never reads them.
  *   D7  Inputs the reference would panic on are rejected by orc_create.
+ *   D8  Math contract v3: RayTracer::rand's polar angle (src/rt.rs:997-1003) is NOT taken as acos, then sin / cos:
+ *       rt_rand computes cos th = 1 - 2 u1 (exact on the 2^-23 lattice of u1) and sin th = sqrt(4 u1 (1 - u1)).
+ *       Bounded by tests/test_oracle_math.py::test_contract_v3_polar_angle over every lattice value of u1:
+ *       <= 3e-7 from the literal om_acosf -> om_sincosf composition, <= 6e-8 from the f64 truth.
+ *       RULE: the restatement of reference arithmetic changes only together with a committed
+ *       bound of this kind and a re-run of all five doc/out*.png pins.
  */
 #define _GNU_SOURCE
 #include "mrt_oracle.h"
@@ -602,11 +608,23 @@ static ray_t camera_ray(const orc_ctx *c, const pixel_cam_t *pc, uint32_t pk)
  * sin th, cos th through libm; here cos th = 1 - 2 u1 (exact: u1 lies on the 2^-23 lattice) and sin th = sqrt(4 u1 (1 - u1))
  * = sqrt((1 - cos th)(1 + cos th)) with both factors exact, one rounding in the product and a correctly rounded root: the same
  * two numbers to within an ulp (the libm composition is off by up to ~1e-7 near the poles, where acos loses the angle). */
+static inline void rt_rand_polar(float u1, float *sth, float *cth)      /* contract v3 (D8) */
+{
+    *cth = 1.0f - 2.0f * u1;
+    *sth = sqrtf((4.0f * u1) * (1.0f - u1));
+}
+/* the literal reading of src/rt.rs:997, 1000-1002: th = acos(1 - 2 u1), then sin th, cos th (contract functions for libm);
+ * kept only so that the test can bound D8 against it */
+static inline void rt_rand_polar_literal(float u1, float *sth, float *cth)
+{
+    float th = om_acosf(1.0f - 2.0f * u1);
+    om_sincosf(th, sth, cth);
+}
 static v3 rt_rand(v3 n, float r, float u1, float u2)
 {
     float phi = u2 * 2.0f * OM_PI;
-    float cth = 1.0f - 2.0f * u1;
-    float sth = sqrtf((4.0f * u1) * (1.0f - u1));
+    float cth, sth;
+    rt_rand_polar(u1, &sth, &cth);
     float sphi, cphi;
     om_sincosf(phi, &sphi, &cphi);
     v3 v = V3(sth * cphi, sth * sphi, cth);
@@ -1087,6 +1105,11 @@ void orc_math(int op, const float *a, const float *b, float *out, size_t n)
         case 5: out[i] = 1.0f / x; break;
         case 6: out[i] = sqrtf(x); break;
         case 7: out[i] = x / y; break;
+        /* the polar angle of RayTracer::rand for u1 = x: contract v3 (8 sin, 9 cos) and the literal composition (10, 11) */
+        case 8: { float s, c; rt_rand_polar(x, &s, &c); out[i] = s; break; }
+        case 9: { float s, c; rt_rand_polar(x, &s, &c); out[i] = c; break; }
+        case 10: { float s, c; rt_rand_polar_literal(x, &s, &c); out[i] = s; break; }
+        case 11: { float s, c; rt_rand_polar_literal(x, &s, &c); out[i] = c; break; }
         default: out[i] = 0.0f;
         }
     }

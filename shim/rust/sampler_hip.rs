@@ -57,7 +57,7 @@ extern "C" {
 
 fn last_error() -> String { unsafe { CStr::from_ptr(mrt_last_error()).to_string_lossy().into_owned() } }
 
-pub struct Sampler { ctx: *mut MrtCtx, seed: u64, print: u64 }
+pub struct Sampler { ctx: *mut MrtCtx, seed: u64, print: u64, stale: bool }
 unsafe impl Send for Sampler {}          // one owner at a time, like &mut self (HttpServer: one Sampler per thread)
 
 /// What the device context was built from: execute() receives scene, frame and rt on EVERY call (src/sampler.rs:28), so
@@ -102,12 +102,13 @@ impl Sampler {
     pub fn new(_workers: u32, _n_dim: usize) -> Sampler {
         let seed = std::env::var("MRT_SEED").ok().and_then(|s| s.parse().ok())
             .unwrap_or_else(|| rand::random::<u64>());          // the reference is unseeded: default stays random
-        Sampler { ctx: std::ptr::null_mut(), seed, print: 0 }
+        Sampler { ctx: std::ptr::null_mut(), seed, print: 0, stale: false }
     }
 
     pub fn execute<'a>(&mut self, scene: &'a Scene, frame: &Frame, rt: &'a RayTracer) -> Duration {
         let print = fingerprint(scene, frame, rt);
-        if self.ctx.is_null() || print != self.print {
+        if self.ctx.is_null() || print != self.print || self.stale {
+            self.stale = false;
             // first call, or the caller passes another scene / frame / rt than last time: the context is (re)built from what
             // is passed NOW.  Like the reference, whose map keeps adding whatever the scene (src/sampler.rs:60-70), the sums
             // accumulated so far are carried over when the supersampled frame keeps its size.
@@ -130,6 +131,11 @@ impl Sampler {
         if unsafe { mrt_execute(self.ctx, 1, &mut secs) } != 0 { panic!("{}", last_error()); }
         Duration::from_secs_f64(secs)
     }
+
+    /// The fingerprint sees bulk data (mesh triangles, texels) by address, length and a strided sample: an in-place edit
+    /// between the sample points goes unnoticed.  A caller that edits such data in place calls this; the next execute()
+    /// rebuilds the context from what it is passed.  (The reference's own callers never edit a scene mid-render.)
+    pub fn invalidate(&mut self) { self.stale = true; }
 
     pub fn img(&self, frame: &Frame) -> Result<RgbImage, String> {
         if self.ctx.is_null() { return Err("img before execute".into()); }

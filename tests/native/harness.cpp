@@ -77,6 +77,12 @@ int main()
             dfr.execute(d2, 1);
             dfr.colors(&c1);
             printf("rebuild contexts %u count %u -> %u\n", dfr.contexts_created(), c0, c1);
+            // an in-place edit of bulk data the strided fingerprint may miss: the caller says so, the next call rebuilds
+            uint32_t c2 = 0;
+            dfr.invalidate();
+            dfr.execute(d2, 1);
+            dfr.colors(&c2);
+            printf("invalidate contexts %u count %u\n", dfr.contexts_created(), c2);
         }
         // error path: emit outside [0,1] is what gen_bool would panic on (src/rt.rs:968)
         r.mat.emit = 2.0f;

@@ -28,6 +28,12 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert d["config"]["samples_per_step"] == 512 * 512 * 64
     r = d["roofline"]
     assert r["gather_ms"] > 0 and 0 < r["kernel_ms_rank_min"] <= r["kernel_ms_rank_max"]
+    assert r["bound"] == "valu_issue" and r["hbm"]["bound"] == "hbm" and 0 < r["frac"] < 1
+    # what the process group saw: the first real SCALE record has to explain itself
+    ds = d["dist"]
+    assert ds["backend"] == "gloo" and ds["world_size"] == 2 and [x["rank"] for x in ds["devices"]] == [0, 1]
+    assert ds["distinct_devices"] == 1 and all(x["device_index"] == 0 for x in ds["devices"])      # the rehearsal layout, and it says so
+    assert ds["gather_bytes_per_rank"] == 256 * 512 * 12 and ds["use_all_gather"] is False
 
 
 def test_bench_many_ranks_rehearsal_of_the_scale_run():
@@ -49,6 +55,10 @@ def test_bench_many_ranks_rehearsal_of_the_scale_run():
     r = d["roofline"]
     assert r["gather_ms"] > 0 and 0 < r["kernel_ms_rank_min"] <= r["kernel_ms_rank_max"]
     assert r["pmc_stale"] is False and r["traffic"] is None          # --spp override: nothing is replayed from a profile
+    assert r["bound"] == "valu_issue" and r["frac_source"] == "flop_model" and r["frac"] == r["valu_model_frac"]
+    ds = d["dist"]
+    assert ds["backend"] == "gloo" and ds["world_size"] == n and len(ds["devices"]) == n
+    assert ds["gather_bytes_per_rank"] == 272 * 1920 * 12            # 135 blocks of 8 rows over 4 ranks: 34 blocks = 272 padded rows
     assert "cpu_baseline" not in d                                    # rank 0 at N = 1 only
 
 
@@ -121,6 +131,8 @@ g.execute(render, n_samples=16)
 st = g.stats()
 assert st["samples"] == 120 * 72 * 16 and st["segments"] > 0
 g.execute(render, n_samples=4)
+g.execute(render, n_samples=0)            # joins the gather without a kernel: its stream is not synchronised by exec_finish,
+assert g.stats()["samples"] == 0          # so the gather events are waited for explicitly (ADVICE r3: hipErrorNotReady)
 got, gcnt = g.accum()
 assert gcnt == cnt == 20
 assert np.array_equal(got, ref)

@@ -107,3 +107,65 @@ def test_c5_mesh_and_minecraft_shapes_band_parity(oracle_mod):
         err = np.nanmax(np.abs(a[band[0]:band[1]] - ref[band[0]:band[1]]))
         print(f"C5 {name} band L-inf {err:.3e}")
         assert err <= 1e-4
+
+
+def test_c1_default_256x256_1spp_bounce1_whole_frame_parity(oracle_mod):
+    """BASELINE.json configs[0] literally: example/Default.json geometry, 256x256, sample = 1, bounce = 1 -- the whole
+    frame against the oracle (65 536 paths), image bytes included."""
+    from micro_raytracer_amd import scenes
+    render, holder = make_holder(scenes.default_scene(res=(256, 256), ssaa=1, sample=1, bounce=1))
+    s = _render(render, 1)
+    a, cnt = s.accum()
+    assert cnt == 1 and a.shape == (256, 256, 3)
+    o = oracle_mod.Oracle(holder, seed=9)
+    o.execute(1)
+    ref, _ = o.accum()
+    err = np.abs(a - ref).max()
+    print(f"C1 L-inf {err:.3e}")
+    assert err <= 1e-4
+    o.set_accum(a, 1)
+    assert np.array_equal(s.img(), o.img())
+
+
+def test_headline_launch_1080p_1024spp_matches_the_oracle_at_its_own_size(oracle_mod):
+    """The configuration bench.py reports (`cornell_1080p_1024spp_b8`: Cornell box, 1920x1080, 1024 spp, 8 bounces) in ONE
+    mrt_execute -- the very launch the headline number comes from: 256-thread persistent workgroups, 8 lanes per pixel
+    (k_split 8: 64 chunk planes + reduce_chunks) -- against the oracle's 1024 sequential sample passes
+    (reference src/cli.rs:162-170, fold src/rt.rs:956-994) on an 8-row band through the spheres."""
+    from micro_raytracer_amd import scenes
+    render, holder = make_holder(scenes.cornell_box(res=(1920, 1080), sample=1024, bounce=8))
+    s = _render(render, 1024, seed=1)
+    st = s.stats()
+    assert st["k_split"] == 8 and st["block_threads"] == 256 and st["launches"] == 1, st
+    assert st["kernel_features"] == 0 and st["scene_in_lds"] == 1
+    a, cnt = s.accum()
+    assert cnt == 1024 and a.shape == (1080, 1920, 3)
+    band = (640, 648)
+    o = oracle_mod.Oracle(holder, seed=1)
+    o.execute(1024, rows=band)
+    ref, _ = o.accum()
+    err = np.abs(a[band[0]:band[1]] - ref[band[0]:band[1]]).max() / 1024
+    print(f"headline band L-inf {err:.3e} (kernel {st['kernel_ms']:.1f} ms)")
+    assert err <= 1e-4
+    o.set_accum(a, 1024)
+    assert np.array_equal(s.img()[band[0]:band[1]], o.img()[band[0]:band[1]])
+
+
+def test_c5_full_width_bands_with_the_sample_split(oracle_mod):
+    """BASELINE.json configs[4] at full width with more than one sample chunk per launch (48 spp = three chunks, so the
+    launch runs with k_split > 1 like the benchmarked 512-spp ones): 2-row bands of the mesh and the Minecraft-shaped
+    scene against the oracle."""
+    from micro_raytracer_amd import scenes
+    for name, desc, band in (("mesh", scenes.mesh_scene(res=(1920, 1080), sample=48), (520, 522)),
+                             ("minecraft", scenes.minecraft_like(res=(1920, 1080), ssaa=2, sample=48), (1300, 1302))):
+        render, holder = make_holder(desc)
+        s = _render(render, 48)
+        st = s.stats()
+        assert st["k_split"] > 1, st
+        a, _ = s.accum()
+        o = oracle_mod.Oracle(holder, seed=9)
+        o.execute(48, rows=band)
+        ref, _ = o.accum()
+        err = np.nanmax(np.abs(a[band[0]:band[1]] - ref[band[0]:band[1]])) / 48
+        print(f"C5 {name} 48 spp band L-inf {err:.3e}, k_split {st['k_split']}, block {st['block_threads']}, features {st['kernel_features']}")
+        assert err <= 1e-4

@@ -31,6 +31,7 @@ def test_cpp_sampler_matches_python_sampler_and_is_thread_safe():
     # description rebuilds the context while the sums are kept (src/sampler.rs:28, 60-70)
     assert kv["deferred"] == "1 eager 0 same 1" and kv["img_deferred"] == kv["img_update"]
     assert kv["rebuild"] == "contexts 2 count 4 -> 5"
+    assert kv["invalidate"] == "contexts 3 count 6"                 # invalidate(): rebuilt although the description did not change
     assert "emit" in kv["error_path"]                               # Err(String) instead of the reference's panic
     from micro_raytracer_amd import Sampler, scenes
     render, _ = make_holder(scenes.default_scene(res=(96, 54), sample=4))

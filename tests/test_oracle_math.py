@@ -86,3 +86,41 @@ def test_rng_contract(oracle_mod):
     a = u.reshape(-1, 10)
     c = np.corrcoef(a.T)
     assert np.abs(c - np.eye(10)).max() < 0.08
+
+
+def test_contract_v3_polar_angle(oracle_mod):
+    """Math contract v3 (oracle D8, DESIGN.md section 4): RayTracer::rand's polar angle (reference src/rt.rs:997-1003) as
+    cos th = 1 - 2 u1, sin th = sqrt(4 u1 (1 - u1)), measured over EVERY value u1 can take (the 2^23 lattice of
+    rand's Uniform<f32>) against (a) the literal reading -- th = acos(1 - 2 u1), then sin th, cos th through the contract's
+    own functions -- and (b) the f64 truth.  This is the committed bound the oracle's restatement may deviate by; a
+    rewrite of rt_rand that is less innocent fails here."""
+    u = (np.arange(1 << 23, dtype=np.float64) * 2.0 ** -23).astype(np.float32)
+    s3, c3 = oracle_mod.math(8, u), oracle_mod.math(9, u)
+    sl, cl = oracle_mod.math(10, u), oracle_mod.math(11, u)
+    u64 = u.astype(np.float64)
+    ct = 1.0 - 2.0 * u64
+    st = np.sqrt(4.0 * u64 * (1.0 - u64))
+    d_lit = max(np.abs(s3.astype(np.float64) - sl).max(), np.abs(c3.astype(np.float64) - cl).max())
+    e_sin, e_cos = np.abs(s3 - st).max(), np.abs(c3 - ct).max()
+    e_sin_lit, e_cos_lit = np.abs(sl - st).max(), np.abs(cl - ct).max()
+    print(f"v3 vs literal {d_lit:.3e}; vs f64: sin {e_sin:.3e} cos {e_cos:.3e} (literal: {e_sin_lit:.3e} / {e_cos_lit:.3e})")
+    assert d_lit <= 3e-7                       # measured 2.98e-7: inside the <= 2 ulp libm-vs-contract divergence D2
+    assert e_cos == 0.0 and e_sin <= 6e-8      # cos exact on the lattice, sin one rounding + a correctly rounded root (5.05e-8)
+    assert e_sin <= e_sin_lit and e_cos <= e_cos_lit      # never further from the truth than the literal composition
+    assert np.all(s3 >= 0.0) and np.all(s3 <= 1.0) and np.all(np.abs(c3) <= 1.0)
+    # unit length to f32 rounding, as sin^2 + cos^2 of one angle would be
+    assert np.abs(s3.astype(np.float64) ** 2 + ct ** 2 - 1.0).max() <= 2e-7
+
+
+def test_oracle_build_takes_mfma_only_from_the_host(oracle_mod):
+    """oracle/Makefile passes -mfma iff the build host's CPU has FMA (without it __builtin_fmaf goes through libm's
+    correctly rounded fmaf: same bits, no SIGILL); the contract's fused steps are exact either way."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(oracle_mod.__file__))
+    cmd = subprocess.run(["make", "-C", here, "-n", "-B", "liboracle.so"], capture_output=True, text=True, check=True).stdout
+    flags = open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split()
+    assert ("-mfma" in cmd.split()) == ("fma" in flags)
+    assert "-ffp-contract=off" in cmd
+    a = np.array([1.0 + 2.0 ** -12], np.float32)
+    assert oracle_mod.math(0, a)[0] == np.float32(np.sin(np.float64(a[0])))      # a fused-step function still rounds as agreed
