@@ -152,16 +152,17 @@ def test_headline_launch_1080p_1024spp_matches_the_oracle_at_its_own_size(oracle
 
 
 def test_c5_full_width_bands_with_the_sample_split(oracle_mod):
-    """BASELINE.json configs[4] at full width with more than one sample chunk per launch (48 spp = three chunks, so the
-    launch runs with k_split > 1 like the benchmarked 512-spp ones): 2-row bands of the mesh and the Minecraft-shaped
-    scene against the oracle."""
+    """BASELINE.json configs[4] at full width with more than one sample chunk per launch (48 spp = three chunks), in the launch
+    shapes the benchmarked 512-spp renders use: the 1080p mesh frame with the sample split (k_split > 1: chunk planes +
+    reduce_chunks), the Minecraft-shaped frame at ssaa 2 (129 600 wave tiles: not split, chunk sums added in place, three
+    chunks per lane).  2-row bands against the oracle."""
     from micro_raytracer_amd import scenes
-    for name, desc, band in (("mesh", scenes.mesh_scene(res=(1920, 1080), sample=48), (520, 522)),
-                             ("minecraft", scenes.minecraft_like(res=(1920, 1080), ssaa=2, sample=48), (1300, 1302))):
+    for name, desc, band, split in (("mesh", scenes.mesh_scene(res=(1920, 1080), sample=48), (520, 522), True),
+                                    ("minecraft", scenes.minecraft_like(res=(1920, 1080), ssaa=2, sample=48), (1300, 1302), False)):
         render, holder = make_holder(desc)
         s = _render(render, 48)
         st = s.stats()
-        assert st["k_split"] > 1, st
+        assert (st["k_split"] > 1) == split, st
         a, _ = s.accum()
         o = oracle_mod.Oracle(holder, seed=9)
         o.execute(48, rows=band)
