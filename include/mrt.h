@@ -265,18 +265,19 @@ int mrt_device_count(void);
 /* Test hook, host only (no device needed): what mrt_create would stage in LDS for this scene and the workgroup shape of its
  * launches -- the policy of csrc/mrt_api.cpp as data, so that it can be checked where no GPU exists. */
 typedef struct mrt_plan {
-    uint32_t staging;        /* 0 whole scene | 1 warm: membership tables and texels in global memory | 2 deep: triangle-BVH
-                                table in level order, only its first tbvh_hot_nodes nodes staged, triangles in global memory |
-                                3 none: everything through L2 */
+    uint32_t staging;        /* 0 whole scene | 1 warm: membership tables and texels in global memory | 2 deep: only the first
+                                tbvh_hot_nodes nodes of the (level-ordered) triangle-BVH table staged, triangles in global
+                                memory | 3 none: everything through L2 */
     uint32_t block_threads;  /* workgroup size of the batched launches */
-    uint32_t lds_bytes;      /* LDS per workgroup: staged scene + lane stash + leaf queues */
+    uint32_t lds_bytes;      /* LDS per workgroup: staged scene + lane stash + walk areas */
     uint32_t staged_bytes;   /* the staged part of the scene */
     uint32_t scene_bytes;    /* the whole packed scene without the octree leaf lists */
     uint32_t kernel_features;/* FEAT template argument of the kernel instantiation (mrt_stats.kernel_features) */
     uint32_t tbvh_nodes;     /* triangle-BVH nodes of all meshes */
     uint32_t tbvh_hot_nodes; /* of which staged (deep level; otherwise all when staged at all) */
     uint32_t small_plain_grid; /* 1: launches of less than one sample chunk take the plain grid instead of the persistent one */
-    uint32_t reserved[3];
+    uint32_t walk_cap;       /* entries of a lane's walk area (node stack + leaf queue of the mesh walk; 0: no mesh walk) */
+    uint32_t reserved[2];
 } mrt_plan;
 int mrt_plan_launch(const mrt_render_desc *desc, mrt_plan *out);
 

@@ -83,7 +83,7 @@ class Stats(C.Structure):
 class Plan(C.Structure):
     _fields_ = [("staging", C.c_uint32), ("block_threads", C.c_uint32), ("lds_bytes", C.c_uint32), ("staged_bytes", C.c_uint32),
                 ("scene_bytes", C.c_uint32), ("kernel_features", C.c_uint32), ("tbvh_nodes", C.c_uint32), ("tbvh_hot_nodes", C.c_uint32),
-                ("small_plain_grid", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("small_plain_grid", C.c_uint32), ("walk_cap", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 STAGING = ("all", "warm", "deep", "none")

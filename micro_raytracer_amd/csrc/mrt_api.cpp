@@ -240,24 +240,30 @@ struct Plan {
 void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
 {
     // ---- what is staged in LDS, and the launch shape -------------------------------------------------------------------
-    // LDS per workgroup = staged scene + lane stash (+ the mesh kernels' leaf queues): pt_lds_bytes knows.  Staging levels:
+    // LDS per workgroup = staged scene + lane stash (+ the mesh kernels' walk areas): pt_lds_bytes knows.  Staging levels:
     //   all     the whole packed scene (minus the octree leaf lists);
-    //   warm    F_COLD: membership tables and texels stay in global memory (touched at most once per shaded hit); the mesh
-    //           kernels spend the freed LDS on a per-lane leaf queue, so a mesh scene prefers this level when it fits;
-    //   deep    F_COLD | F_DEEP: meshes beyond the LDS.  The scene is packed again with the triangle-BVH table in level order
-    //           and as many of its first nodes -- the top levels of every tree -- as fit next to the small tables are staged;
-    //           deeper nodes and the triangles are read from global memory too;
+    //   warm    F_COLD: membership tables and texels stay in global memory (touched at most once per shaded hit);
+    //   deep    F_COLD | F_DEEP: meshes beyond the LDS.  The triangle-BVH table is in level order, so as many of its first
+    //           nodes -- the top levels of every tree -- as fit next to the small tables are staged; deeper nodes and the
+    //           triangles are read from global memory too;
     //   none    everything through L2 (the small tables themselves do not fit).
     // Launch shape, chosen for resident wavefronts per CU (the kernel is VALU-issue bound and wants >= 16): the smallest
     // workgroup that reaches 16 waves per CU wins (smaller workgroups balance better), else the shape with the most:
     //   256 threads (2x2 wave tiles of 8x8 pixels) + 10 KB lane stash per copy of the scene (64-thread workgroups -- one
-    //   wavefront, its own 5.5 KB of LDS -- served small scenes until round 3 and remain as a forced shape for the tests);
+    //   wavefront, its own 5.5 KB of LDS -- remain as a forced shape for the tests);
     //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves.
+    // Mesh kernels of the warm and deep levels own a per-lane walk area (Params.walk_cap entries, mrt_trace.h): the leaf queue
+    // of the binary walk (8 entries, warm), or node stack + leaf queue of the 4-wide walk (12 entries, deep: the scene is
+    // packed again with 4-wide triangle BVHs).
     // Environment (experiments, tests; read here, once): MRT_COLD=0/1 forbids / forces the warm level, MRT_DEEP_NODES=n forces
-    // the deep level with n staged nodes, MRT_SCENE_IN_L2 forces none, MRT_BLOCK_THREADS forces a workgroup size.
+    // the deep level with n staged nodes, MRT_SCENE_IN_L2 forces none, MRT_BLOCK_THREADS forces a workgroup size, MRT_WALK_CAP
+    // the entries of the deep level's walk area.
     const bool no_lds = getenv("MRT_SCENE_IN_L2") != nullptr;
     const char *force = getenv("MRT_BLOCK_THREADS");
     const bool mesh_walk = pk.n_tbvh_nodes != 0u && (pk.features & 3u) == 3u;
+    u32 deep_cap = kWalkCapDefault;
+    if (const char *fw = getenv("MRT_WALK_CAP")) { const int v = atoi(fw); if (v >= 4 && v <= (int)kWalkCapMax) deep_cap = (u32)v; }
+    pk.P.walk_cap = mesh_walk ? kLeafQueue : 0u;         // (only kernels with a walk area count it: pt_lds_bytes)
     auto lds_of = [&](u32 shape, u32 marker) { return pt_lds_bytes(pk.P, shape, true, (pk.features & 31u) | marker); };
     auto fits = [&](u32 shape, u32 marker) { return lds_of(shape, marker) <= kLdsLimit; };
     auto fits_any = [&](u32 marker) { return fits(256u, marker) || fits(512u, marker) || fits(1024u, marker); };
@@ -287,25 +293,28 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
         else if (mesh_walk) cold = kDeep;
         else in_lds = false;
         if (cold == kDeep) {
-            const size_t stash1024 = (size_t)ST_SLOTS * 1024u * sizeof(float);               // lane stash of one 1024-thread workgroup
-            PackOpts po; po.tbvh_level_order = true;
+            // packed again with 4-wide triangle BVHs in level order; everything hot in front of the node table + lane stash +
+            // walk areas of one 1024-thread workgroup; the rest of the LDS holds the first nodes of the table
+            PackOpts po; po.tbvh_wide = true;
             Packed again; std::string err2;
-            bool ok2 = pack_scene(desc, again, err2, po) == MRT_OK && again.tbvh_level_order;
-            const size_t front = ok2 ? (size_t)again.P.off_tbvh * 4 : 0;                         // everything hot in front of the node table
-            ok2 = ok2 && front + stash1024 + 1024 < kLdsLimit;
+            bool ok2 = pack_scene(desc, again, err2, po) == MRT_OK && again.tbvh_wide;
+            const size_t fixed = (size_t)ST_SLOTS * 1024u * sizeof(float) + (size_t)deep_cap * 1024u * sizeof(u32) + 1024u;
+            const size_t front = ok2 ? (size_t)again.P.off_tbvh * 4 : 0;
+            ok2 = ok2 && front + fixed < kLdsLimit;
             if (ok2) {
-                const size_t room = (kLdsLimit - stash1024 - 1024 - front) / (BVH_WORDS * 4);
+                const size_t room = (kLdsLimit - fixed - front) / (B4_WORDS * 4);
                 size_t n = fd ? (size_t)strtoul(fd, nullptr, 10) : room;
                 if (n > room) n = room;
                 if (n > again.n_tbvh_nodes) n = again.n_tbvh_nodes;
                 const u32 n_mesh = (again.P.off_node - again.P.off_mesh) / MESH_WORDS;
-                ok2 = n >= n_mesh && n_mesh > 0u;            // every root is staged (the walk reads it from LDS unconditionally)
+                ok2 = n >= n_mesh && n_mesh > 0u;            // every root is staged
                 if (ok2) {
                     const u32 keep = pk.features;
                     pk = again;
                     pk.features = keep;
+                    pk.P.walk_cap = deep_cap;
                     pk.P.n_tbvh_hot = (u32)n;
-                    pk.P.lds_words_hot = (pk.P.off_tbvh + (u32)n * BVH_WORDS + 3u) & ~3u;
+                    pk.P.lds_words_hot = (pk.P.off_tbvh + (u32)n * B4_WORDS + 3u) & ~3u;
                 }
             }
             if (!ok2) { cold = 0u; in_lds = false; }
@@ -350,7 +359,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     const int rc = pack_scene(desc, c->pk, err);
     if (rc != MRT_OK) { fail(rc, "mrt_create: %s", err.c_str()); delete c; return nullptr; }
     Plan plan;
-    plan_launch(desc, c->pk, plan);          // may re-pack the scene (deep staging): before anything is uploaded
+    plan_launch(desc, c->pk, plan);          // may re-pack the scene (deep staging: 4-wide triangle BVHs), before anything is uploaded
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -1032,6 +1041,7 @@ int mrt_plan_launch(const mrt_render_desc *desc, mrt_plan *out)
     out->tbvh_nodes = n_nodes;
     out->tbvh_hot_nodes = !pl.in_lds ? 0u : ((pk.features & 128u) ? pk.P.n_tbvh_hot : n_nodes);
     out->small_plain_grid = pl.small_plain_grid ? 1u : 0u;
+    out->walk_cap = pk.P.walk_cap;
     ok();
     return MRT_OK;
 }

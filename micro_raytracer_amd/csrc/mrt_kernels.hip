@@ -90,12 +90,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT, BLOCK_THREADS))
 #endif
     S.G = reinterpret_cast<const float *>(blob_g);
     S.P = &P;
-    // behind the staged scene (16-byte aligned): [lane stash: ST_SLOTS x blockDim floats] [leaf queues: kQ x blockDim words]
+    // behind the staged scene (16-byte aligned): [lane stash: ST_SLOTS x blockDim floats] [walk areas: P.walk_cap x blockDim words]
     const u32 stash_base4 = (staged_words + 3u) >> 2;
     constexpr bool kStash = lds_stash_for(SCENE_IN_LDS, BLOCK_THREADS, FEAT);
-    S.lq = nullptr; S.lq_stride = BLOCK_THREADS;
-    if constexpr (leaf_queue_for(FEAT) != 0u)
-        S.lq = (void *)(reinterpret_cast<float *>(lds_blob + stash_base4) + (kStash ? stash_slots_for(FEAT, BLOCK_THREADS) * BLOCK_THREADS : 0u) + threadIdx.x);
+    S.wk = nullptr; S.wk_stride = BLOCK_THREADS;
+    if constexpr (has_walk_area(FEAT))
+        S.wk = (void *)(reinterpret_cast<float *>(lds_blob + stash_base4) + (kStash ? stash_slots_for(FEAT, BLOCK_THREADS) * BLOCK_THREADS : 0u) + threadIdx.x);
     u32 segments = 0;
 #ifdef MRT_PHASE_TIMING
     unsigned long long wave_ticks[4] = {0ull, 0ull, 0ull, 0ull};
@@ -317,7 +317,7 @@ size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 f
     size_t lds = scene_in_lds ? (size_t)staged_words_for(P, inst) * 4u : 0u;
     lds = (lds + 15u) & ~(size_t)15u;
     if (lds_stash_for(scene_in_lds, (int)block_threads, inst)) lds += (size_t)stash_slots_for(inst, block_threads) * block_threads * sizeof(float);
-    lds += (size_t)leaf_queue_for(inst) * block_threads * sizeof(u32);
+    if (has_walk_area(inst)) lds += (size_t)P.walk_cap * block_threads * sizeof(u32);
     return lds;
 }
 

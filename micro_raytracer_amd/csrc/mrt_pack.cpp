@@ -267,6 +267,62 @@ bool build_tbvh(const float *tris, u32 n_tris, std::vector<float> &nodes, std::v
     return true;
 }
 
+// ---- 4-wide collapse of the binary triangle BVH (mrt_scene.h) ----
+// `bin` is build_tbvh's depth-first threaded table (mesh-relative skip links: children of an internal node n are n + 1 and
+// skip(n + 1)).  A 4-wide node takes the two children of a binary node and keeps opening the internal slot with the largest
+// box until four slots are full (or only leaves remain).  Returns the nodes in creation order (node 0 = root) with child
+// words whose internal form holds the LOCAL node index; depth[] is each node's level.
+namespace {
+struct Wide4 {
+    float c[4][3], h[4][3];
+    u32 child[4];              // 0 empty | leaf word | B4_INTERNAL | local index
+    u32 depth;
+};
+struct Collapse4 {
+    const std::vector<float> &bin;
+    std::vector<Wide4> out;
+    u32 skip_of(u32 n) const { return bits(bin[(size_t)n * BVH_WORDS + BVH_SKIP]); }
+    u32 leaf_of(u32 n) const { return bits(bin[(size_t)n * BVH_WORDS + BVH_LEAF]); }
+    double area_of(u32 n) const
+    {
+        const float *q = bin.data() + (size_t)n * BVH_WORDS;
+        const double x = q[BVH_H], y = q[BVH_H + 1], z = q[BVH_H + 2];
+        return x * y + y * z + z * x;
+    }
+    u32 make(u32 bnode, u32 depth)
+    {
+        const u32 me = (u32)out.size();
+        out.emplace_back();
+        std::vector<u32> slots;
+        if (leaf_of(bnode) != 0u) slots.push_back(bnode);                       // a one-leaf mesh: the root holds it
+        else { slots.push_back(bnode + 1u); slots.push_back(skip_of(bnode + 1u)); }
+        while (slots.size() < 4u) {
+            int pick = -1;
+            double best = -1.0;
+            for (size_t k = 0; k < slots.size(); ++k) if (leaf_of(slots[k]) == 0u && area_of(slots[k]) > best) { best = area_of(slots[k]); pick = (int)k; }
+            if (pick < 0) break;
+            const u32 n = slots[pick];
+            slots[pick] = n + 1u;                                               // the opened slot keeps its place, its sibling follows
+            slots.insert(slots.begin() + pick + 1, skip_of(n + 1u));
+        }
+        // internal children first (in their depth-first order), leaves behind them: the internal children of a node are then
+        // consecutive nodes of the level-ordered table, child k at (first child) + k -- what lets ONE stack entry of the
+        // walk stand for all pending siblings (mrt_trace.h mesh_isect)
+        std::stable_partition(slots.begin(), slots.end(), [&](u32 n) { return leaf_of(n) == 0u; });
+        Wide4 w;
+        memset(&w, 0, sizeof w);
+        w.depth = depth;
+        for (size_t k = 0; k < slots.size(); ++k) {
+            const float *q = bin.data() + (size_t)slots[k] * BVH_WORDS;
+            for (int a = 0; a < 3; ++a) { w.c[k][a] = q[BVH_C + a]; w.h[k][a] = q[BVH_H + a]; }
+            w.child[k] = leaf_of(slots[k]) != 0u ? leaf_of(slots[k]) : (B4_INTERNAL | make(slots[k], depth + 1u));
+        }
+        out[me] = w;
+        return me;
+    }
+};
+}  // namespace
+
 // image 0.24 imageops::sample: per-output-index taps of horizontal_sample / vertical_sample
 void lanczos3_taps(u32 src, u32 dst, ResampleTaps &out)
 {
@@ -409,6 +465,8 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
     struct Bound { float mn[3], mx[3]; bool ok; };
     std::vector<Bound> bounds;           // world-space box of every flat instance (ok = false: cannot be bounded)
     std::vector<float> tri_tab, node_tab, tbvh_tab;
+    std::vector<std::vector<Wide4>> wide;       // per mesh with a triangle BVH: its 4-wide nodes (local child indices)
+    std::vector<u32> wide_mesh;                 // ... and the mesh-table record it belongs to
     std::vector<u32> memb_tab, membe_tab, parent_tab;
     u32 n_inst_total = 0;
     for (u32 r = 0; r < sc.n_renderer; ++r) {
@@ -479,15 +537,27 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
             }
             for (u32 t = 0; tb_ok && t < o.n_tris; ++t) if (memb[t].size() > 255u) tb_ok = false;
             if (tb_ok && membe_tab.size() + oc.leaf_ids.size() >= (1u << 24)) tb_ok = false;
-            const u32 tb0 = (u32)(tbvh_tab.size() / BVH_WORDS);
+            float mesh_c[3] = {0, 0, 0}, mesh_h[3] = {0, 0, 0};
+            u32 mesh_tb = NO_NODE;
             if (tb_ok) {
-                const u32 nn = (u32)(tbn.size() / BVH_WORDS);
-                for (u32 k = 0; k < nn; ++k) {
-                    float *q = tbn.data() + (size_t)k * BVH_WORDS;
-                    const u32 skip = bits(q[BVH_SKIP]);
-                    q[BVH_SKIP] = fbits(skip >= nn ? BVH_END : tb0 + skip);
+                for (int a = 0; a < 3; ++a) { mesh_c[a] = tbn[BVH_C + a]; mesh_h[a] = tbn[BVH_H + a]; }      // bounds of the mesh = the root's box
+                if (opts.tbvh_wide) {
+                    // 4-wide collapse (emitted below, the nodes of all meshes in level order)
+                    Collapse4 col{tbn, {}};
+                    col.make(0u, 0u);
+                    wide_mesh.push_back((u32)(mesh_tab.size() / MESH_WORDS));
+                    wide.push_back(std::move(col.out));
+                } else {
+                    // binary threaded table: mesh-relative skip links -> absolute
+                    mesh_tb = (u32)(tbvh_tab.size() / BVH_WORDS);
+                    const u32 nn = (u32)(tbn.size() / BVH_WORDS);
+                    for (u32 k = 0; k < nn; ++k) {
+                        float *q = tbn.data() + (size_t)k * BVH_WORDS;
+                        const u32 skip = bits(q[BVH_SKIP]);
+                        q[BVH_SKIP] = fbits(skip >= nn ? BVH_END : mesh_tb + skip);
+                    }
+                    tbvh_tab.insert(tbvh_tab.end(), tbn.begin(), tbn.end());
                 }
-                tbvh_tab.insert(tbvh_tab.end(), tbn.begin(), tbn.end());
             }
             for (u32 t = 0; t < o.n_tris; ++t) {
                 u32 head = 0;
@@ -502,8 +572,10 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
             mesh_tab.push_back(o.n_tris);
             mesh_tab.push_back(oc.root == NO_NODE ? NO_NODE : node0 + oc.root);
             mesh_tab.push_back(leaf0);
-            mesh_tab.push_back(tb_ok ? tb0 : NO_NODE);
-            mesh_tab.push_back(0); mesh_tab.push_back(0); mesh_tab.push_back(0);
+            mesh_tab.push_back(mesh_tb);                       // MESH_TBVH (wide table: set when its nodes are laid out)
+            mesh_tab.push_back(0);
+            for (int a = 0; a < 3; ++a) mesh_tab.push_back(bits(mesh_c[a]));
+            for (int a = 0; a < 3; ++a) mesh_tab.push_back(bits(mesh_h[a]));
             node_tab.insert(node_tab.end(), oc.nodes.begin(), oc.nodes.end());
             for (u32 id : oc.leaf_ids) leaf_tab.push_back(new_of[id]);
             for (u32 t = 0; t < o.n_tris; ++t) {
@@ -641,30 +713,29 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
     B.w.resize(B.w.size() + (size_t)sc.n_textures * TEX_WORDS, 0);
     P.off_lut = B.align4();
     for (int k = 0; k < 256; ++k) B.f((float)k / 255.0f);
-    if (opts.tbvh_level_order && !tbvh_tab.empty()) {
-        // depth-first table (first child = node + 1) -> level order over all meshes, explicit child links
-        const u32 nn = (u32)(tbvh_tab.size() / BVH_WORDS);
-        std::vector<u32> depth(nn, 0), newi(nn, 0), roots;
-        for (size_t k = 0; k + MESH_WORDS <= mesh_tab.size(); k += MESH_WORDS) if (mesh_tab[k + MESH_TBVH] != NO_NODE) roots.push_back(mesh_tab[k + MESH_TBVH]);
-        // children of n (internal): n + 1 and skip(n + 1); depth by one pass in index order (parents precede children)
-        auto skip_of = [&](u32 n) { return bits(tbvh_tab[(size_t)n * BVH_WORDS + BVH_SKIP]); };
-        auto leaf_of = [&](u32 n) { return bits(tbvh_tab[(size_t)n * BVH_WORDS + BVH_LEAF]); };
-        for (u32 n = 0; n < nn; ++n) if (leaf_of(n) == 0u) { depth[n + 1] = depth[n] + 1; depth[skip_of(n + 1)] = depth[n] + 1; }
-        std::vector<u32> order(nn);
-        for (u32 n = 0; n < nn; ++n) order[n] = n;
-        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return depth[a] < depth[b]; });   // siblings stay adjacent-ish: index order within a level
-        for (u32 k = 0; k < nn; ++k) newi[order[k]] = k;
-        std::vector<float> re(tbvh_tab.size());
-        for (u32 n = 0; n < nn; ++n) {
-            float *q = re.data() + (size_t)newi[n] * BVH_WORDS;
-            memcpy(q, tbvh_tab.data() + (size_t)n * BVH_WORDS, BVH_WORDS * sizeof(float));
-            const u32 sk = skip_of(n);
-            q[BVH_SKIP] = fbits(sk == BVH_END ? BVH_END : newi[sk]);
-            if (leaf_of(n) == 0u) q[BVH_LEAF] = fbits(BVH_INTERNAL | newi[n + 1]);
+    if (opts.tbvh_wide) {
+        // the 4-wide nodes of all meshes in level order (roots first): a prefix of the table is the top of every tree
+        struct Ref { u32 depth, mesh, local; };
+        std::vector<Ref> order;
+        std::vector<std::vector<u32>> newi(wide.size());
+        for (size_t m = 0; m < wide.size(); ++m) { newi[m].resize(wide[m].size()); for (size_t k = 0; k < wide[m].size(); ++k) order.push_back({wide[m][k].depth, (u32)m, (u32)k}); }
+        std::stable_sort(order.begin(), order.end(), [](const Ref &a, const Ref &b) { return a.depth < b.depth; });     // creation order within a level
+        if (order.size() >= (1u << 24)) { err = "triangle BVHs too large"; return MRT_ERR_LIMIT; }      // node index << 4 | mask in a stack entry
+        for (size_t k = 0; k < order.size(); ++k) newi[order[k].mesh][order[k].local] = (u32)k;
+        tbvh_tab.assign(order.size() * B4_WORDS, 0.0f);
+        for (size_t k = 0; k < order.size(); ++k) {
+            const Wide4 &w = wide[order[k].mesh][order[k].local];
+            float *q = tbvh_tab.data() + k * B4_WORDS;
+            for (int c = 0; c < 4; ++c) {
+                q[B4_CX + c] = w.c[c][0]; q[B4_CY + c] = w.c[c][1]; q[B4_CZ + c] = w.c[c][2];
+                q[B4_HX + c] = w.h[c][0]; q[B4_HY + c] = w.h[c][1]; q[B4_HZ + c] = w.h[c][2];
+                u32 cw = w.child[c];
+                if (cw & B4_INTERNAL) cw = B4_INTERNAL | newi[order[k].mesh][cw & ~B4_INTERNAL];
+                q[B4_CHILD + c] = fbits(cw);
+            }
         }
-        tbvh_tab.swap(re);
-        for (size_t k = 0; k + MESH_WORDS <= mesh_tab.size(); k += MESH_WORDS) if (mesh_tab[k + MESH_TBVH] != NO_NODE) mesh_tab[k + MESH_TBVH] = newi[mesh_tab[k + MESH_TBVH]];
-        out.tbvh_level_order = true;
+        for (size_t m = 0; m < wide.size(); ++m) mesh_tab[(size_t)wide_mesh[m] * MESH_WORDS + MESH_TBVH] = newi[m][0];
+        out.tbvh_wide = true;
     }
     P.off_mesh = B.align4(); B.w.insert(B.w.end(), mesh_tab.begin(), mesh_tab.end());
     P.off_node = B.align4(); for (float v : node_tab) B.f(v);
@@ -711,7 +782,8 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
     P.lds_words = P.off_leaf;
     B.align4();
     P.blob_words = (u32)B.w.size();
-    out.n_tbvh_nodes = (u32)(tbvh_tab.size() / BVH_WORDS);
+    P.walk_cap = tbvh_tab.empty() ? 0u : (out.tbvh_wide ? kWalkCapDefault : 8u);      // mrt_create adjusts it to the LDS budget (plan_launch)
+    out.n_tbvh_nodes = (u32)(tbvh_tab.size() / (out.tbvh_wide ? B4_WORDS : BVH_WORDS));
     out.blob.swap(B.w);
     out.n_nodes = (u32)(node_tab.size() / NODE_WORDS);
     out.n_leaf_ids = (u32)leaf_tab.size();

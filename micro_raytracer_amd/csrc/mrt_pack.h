@@ -16,15 +16,14 @@ struct Packed {
     u32 res_w = 0, res_h = 0;
     float gamma = 0, exp = 0;
     u32 features = 0;            // F_* bits of mrt_trace.h the scene needs
-    bool tbvh_level_order = false;   // the triangle-BVH table is in level order with explicit child links (PackOpts)
+    bool tbvh_wide = false;      // the triangle-BVH table is the 4-wide one (PackOpts)
     u32 n_tex_u8 = 0, n_tex_f32 = 0, n_nodes = 0, n_leaf_ids = 0, n_tris = 0, n_xf = 0, n_bvh_nodes = 0, n_lin = 0, n_tbvh_nodes = 0;
 };
 
 struct PackOpts {
-    // Triangle BVHs in LEVEL order with explicit child links (mrt_scene.h): the table starts with the top levels of every
-    // mesh, so that a prefix of it -- whatever the LDS has room for -- can be staged while the deeper nodes stay in global
-    // memory (kernels built with F_DEEP).  Default: depth-first order, first child = node + 1 (everything fits the LDS).
-    bool tbvh_level_order = false;
+    // Triangle BVHs as the 4-WIDE table of mrt_scene.h (nodes of all meshes in level order, so that a prefix of the table is
+    // the top of every tree) instead of the binary threaded one: for kernels built with F_DEEP, i.e. meshes beyond the LDS.
+    bool tbvh_wide = false;
 };
 
 // Returns MRT_OK or an MRT_ERR_* code with a message in err.
@@ -39,7 +38,8 @@ struct OctreeFlat {
 };
 void build_octree(const float *tris, u32 n_tris, OctreeFlat &out);
 
-// Triangle BVH of one mesh (mrt_scene.h, mesh-relative skip links); order[new id] = old id.  False: mesh cannot be bounded.
+// Binary sweep-SAH triangle BVH of one mesh (depth-first, mesh-relative skip links; pack_scene collapses it into the 4-wide
+// table of mrt_scene.h); order[new id] = old id.  False: mesh cannot be bounded.
 bool build_tbvh(const float *tris, u32 n_tris, std::vector<float> &nodes, std::vector<u32> &order);
 
 // Lanczos3 resampling taps of image 0.24's imageops::resize for one axis (src/sampler.rs:98).

@@ -24,7 +24,7 @@ constexpr u32 XF_WORDS = 20;
 constexpr u32 MAT_WORDS = 16;
 constexpr u32 LIGHT_WORDS = 8;
 constexpr u32 TEX_WORDS = 4;
-constexpr u32 MESH_WORDS = 8;
+constexpr u32 MESH_WORDS = 12;
 constexpr u32 TRI_WORDS = 9;
 constexpr u32 NODE_WORDS = 8;
 
@@ -61,8 +61,9 @@ enum : u32 { TEX_W = 0, TEX_H = 1, TEX_OFF = 2, TEX_FMT = 3 };
 enum : u32 { TEXFMT_NONE = 0, TEXFMT_F32 = 1, TEXFMT_U8 = 2 };
 
 // MESH: [0] first triangle [1] triangle count [2] root node (0xffffffff: no octree) [3] leaf-id base
-//       [4] root node of the triangle BVH (0xffffffff: none)  [5..7] unused
-enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4 };
+//       [4] root of the mesh's triangle BVH: node index in the TBVH table, binary or 4-wide (0xffffffff: none)  [5] unused
+//       [6..8] centre, [9..11] half size of the mesh's bounds in mesh coordinates (the culling margin of a ray is derived from them)
+enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4, MESH_BC = 6, MESH_BH = 9 };
 constexpr u32 NO_NODE = 0xffffffffu;
 
 // NODE: [0..2] 0.5*aabb  [3..5] rel_pos  [6] first child node | first leaf id  [7] count | leaf<<31
@@ -73,10 +74,9 @@ enum : u32 { NODE_HALF = 0, NODE_REL = 3, NODE_FIRST = 6, NODE_COUNT = 7 };
 // 0 for an internal node (next = this + 1), else count << 24 | first index into the instance-id list.
 // Instances that cannot be bounded (planes, non-orthonormal transforms) are in the linear list instead.
 //
-// Triangle BVH of a mesh (TBVH, same node record, mesh-local coordinates, leaf word = count << 24 | first triangle of the
-// mesh): a pure accelerator for Renderer::intersect on meshes.  The reference answers with the first minimum / last
-// maximum of the triangle hits among the *candidates* its octree walk collects (src/rt.rs:740-770); a triangle is a
-// candidate when the ray passes the exact box tests of the root, ..., leaf chain of some octree leaf listing it.  The
+// Triangle BVH of a mesh (TBVH): a pure accelerator for Renderer::intersect on meshes.  The reference answers with the first
+// minimum / last maximum of the triangle hits among the *candidates* its octree walk collects (src/rt.rs:740-770); a triangle
+// is a candidate when the ray passes the exact box tests of the root, ..., leaf chain of some octree leaf listing it.  The
 // kernel finds the triangles the ray can hit through the TBVH (conservative culling), runs the exact triangle test and
 // then decides candidacy from the membership table, so no box the ray misses and no triangle it misses is touched:
 //   MEMB  (one word per triangle, off_memb + MESH_TRI0 + id): count << 24 | first entry
@@ -85,12 +85,26 @@ enum : u32 { NODE_HALF = 0, NODE_REL = 3, NODE_FIRST = 6, NODE_COUNT = 7 };
 //   PARENT (one word per octree node, off_parent + node): parent node, NO_NODE for a root
 // The mesh's triangles are stored in TBVH leaf order; the octree leaf lists hold the permuted ids (a relabelling the
 // reference cannot observe: ids only select a triangle and are compared for equality, src/rt.rs:756).
-// Level-ordered variant of the TBVH table (PackOpts::tbvh_level_order, kernels with F_DEEP): the nodes of ALL meshes sorted
-// by depth (roots first), the leaf word of an internal node = 0x80000000 | index of its first child (the second child is the
-// first one's skip link), skip links unchanged in meaning.  Nodes below Params.n_tbvh_hot are staged in LDS, the rest is
-// read from global memory: the top of every tree, which every walk passes, stays in LDS whatever the size of the meshes.
+//
+// Two forms of the table (pack_scene PackOpts::tbvh_wide; mrt_create picks by where the mesh lives):
+// BINARY (meshes in LDS): the node record of the instance BVH above, mesh-local coordinates, leaf word = count << 24 | first
+// triangle of the mesh, threaded in depth-first order.
+// 4-WIDE (meshes beyond the LDS, kernels with F_DEEP): a node holds the boxes of its (up to) four children, so one visit -- one
+// round of independent 16-byte reads -- decides four subtrees, and only children whose box the ray hits are ever visited: a
+// fifth of the dependent round trips of the binary walk.  Node = B4_WORDS words, structure of arrays so that every read is an
+// aligned 16-byte one (28 words: an odd multiple of 4, which spreads the nodes different lanes read over 16 bank groups):
+//   [0..3] centre x of child 0..3  [4..7] centre y  [8..11] centre z  [12..15] half size x  [16..19] y  [20..23] z
+//   [24..27] child word: 0 = empty slot; leaf: count << 24 | first triangle of the mesh (count 1..4, bit 31 clear);
+//            internal: B4_INTERNAL | INDEX of the child node inside the TBVH table.  Internal children come first and are
+//            consecutive nodes of the table: child k of a node is node (index of child 0) + k
+// Built by collapsing the sweep-SAH binary tree (the child with the largest box is opened until four slots are full); the
+// nodes of ALL meshes are stored in level order (roots first), so that a PREFIX of the table is the top of every tree:
+// the first Params.n_tbvh_hot nodes are staged, the rest is read from global memory.
+constexpr u32 B4_WORDS = 28;
+constexpr u32 B4_INTERNAL = 0x80000000u;
+constexpr u32 kWalkCapMin = 8u, kWalkCapMax = 16u, kWalkCapDefault = 12u;      // entries of a lane's walk area (Params.walk_cap)
+enum : u32 { B4_CX = 0, B4_CY = 4, B4_CZ = 8, B4_HX = 12, B4_HY = 16, B4_HZ = 20, B4_CHILD = 24 };
 constexpr u32 BVH_WORDS = 8;
-constexpr u32 BVH_INTERNAL = 0x80000000u;
 constexpr u32 MEMB_SLOT_BITS = 22u, MEMB_SLOT_MASK = (1u << MEMB_SLOT_BITS) - 1u;
 enum : u32 { BVH_C = 0, BVH_H = 3, BVH_SKIP = 6, BVH_LEAF = 7 };
 constexpr u32 BVH_END = 0xffffffffu;
@@ -124,6 +138,8 @@ struct Params {
     u32 off_rend, off_inst, off_instx, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
     u32 off_tbvh, off_memb, off_membe, off_parent;
     u32 n_tbvh_hot;           // F_DEEP: triangle-BVH nodes with index < n_tbvh_hot are in LDS (set by mrt_create from the LDS budget)
+    u32 walk_cap;             // entries of the per-lane walk area of the mesh kernels (LDS column: node stack from the bottom, leaf
+                              // queue from the top; mrt_trace.h mesh_isect), set by mrt_create from the LDS budget
     u32 blob_words;
     u32 lds_words;            // words a workgroup stages in LDS: everything before the octree leaf lists when every mesh has a
                               // triangle BVH (the lists are then only read, from global memory, by rays that cannot be culled)

@@ -27,15 +27,17 @@ enum : u32 {
     F_BVH = 16u,      // many instances: a BVH over them replaces most of the linear scan (only built with F_ALL)
     F_NOSTASH = 32u,  // launch-shape marker, not a scene feature: 1024-thread workgroup whose scene leaves no LDS for the lane stash
     F_COLD = 64u,     // launch-shape marker: membership tables and texels are read from global memory, not staged in LDS
-                      // (Params.lds_words_warm); the mesh kernels use the freed LDS for a per-lane queue of postponed leaves
-    F_DEEP = 128u     // with F_COLD, meshes beyond the LDS: triangles stay in global memory too (Params.lds_words_hot) and the
-                      // triangle-BVH table is in level order with explicit child links (mrt_scene.h), of which only the first
-                      // Params.n_tbvh_hot nodes -- the top levels of every tree -- are staged
+                      // (Params.lds_words_warm)
+    F_DEEP = 128u     // with F_COLD, meshes beyond the LDS: triangles stay in global memory too (Params.lds_words_hot) and of the
+                      // (level-ordered) triangle-BVH table only the first Params.n_tbvh_hot nodes -- the top levels of every
+                      // tree -- are staged
 };
 // words of the packed scene a kernel instantiation stages in LDS
 MRT_HD u32 staged_words_for(const Params &P, u32 feat) { return (feat & F_DEEP) ? P.lds_words_hot : ((feat & F_COLD) ? P.lds_words_warm : P.lds_words); }
-// entries of the per-lane leaf queue (LDS, behind the lane stash) of the closest-hit mesh walk; 0: no queue, two leaves in registers
-constexpr u32 leaf_queue_for(u32 feat) { return ((feat & F_COLD) && !(feat & F_DEEP) && (feat & F_TRI) && (feat & F_BOX)) ? 8u : 0u; }
+// Mesh kernels that leave the cold tables out of LDS spend it on a per-lane WALK AREA (behind the lane stash), Params.walk_cap
+// entries per lane: the leaf queue of the binary walk (kLeafQueue entries), or (F_DEEP) node stack + leaf queue of the 4-wide walk.
+constexpr bool has_walk_area(u32 feat) { return (feat & F_TRI) && (feat & F_BOX) && (feat & F_COLD); }
+constexpr u32 kLeafQueue = 8u;
 
 // Divergence probe: only the x86 build of tests/emu defines MRT_PROBE(phase); in the kernel it is nothing.
 #ifndef MRT_PROBE
@@ -62,10 +64,7 @@ constexpr u32 leaf_queue_for(u32 feat) { return ((feat & F_COLD) && !(feat & F_D
 #ifndef MRT_PROBE_ROUND                // one round of a lane's triangle-BVH walk: box steps taken, triangles tested, membership boxes
 #define MRT_PROBE_ROUND(steps, tris, membs)
 #endif
-#ifndef MRT_PROBE_TBVH_PART            // (node, first node of the root's right subtree): which half of a triangle BVH is being walked
-#define MRT_PROBE_TBVH_PART(node, right0)
-#endif
-enum : u32 { CT_TRACE = 0, CT_LIN_TEST, CT_BVH_NODE, CT_BVH_TEST, CT_MESH_CALL, CT_MESH_ROOT_HIT, CT_TBVH_NODE, CT_TBVH_TRI, CT_TBVH_TRI_HIT, CT_MEMB_BOX, CT_TRACE_ANY, CT_COUNT };
+enum : u32 { CT_TRACE = 0, CT_LIN_TEST, CT_BVH_NODE, CT_BVH_TEST, CT_MESH_CALL, CT_MESH_ROOT_HIT, CT_TBVH_NODE, CT_TBVH_TRI, CT_TBVH_TRI_HIT, CT_MEMB_BOX, CT_TRACE_ANY, CT_WALK_OVERFLOW, CT_WALK_ROUND, CT_COUNT };
 enum : u32 { PH_ITER = 0, PH_REGEN, PH_SPHERE_MATH, PH_PLANE_HIT, PH_SHADE, PH_NORMAL_NONPLANE, PH_SCATTER1, PH_SCATTER2, PH_REFRACT, PH_EMIT_END, PH_LIGHTS, PH_COUNT };
 
 constexpr float kE = 0.0001f;                 // src/rt.rs:7
@@ -103,6 +102,20 @@ MRT_HD bool nzfin(float x)
 #endif
 }
 MRT_HD bool nzfin3(V3 v) { return nzfin(v.x) && nzfin(v.y) && nzfin(v.z); }
+// 24-bit multiply (v_mul_u32_u24: full rate, where v_mul_lo_u32 is not); both factors below 2^24
+MRT_HD u32 mul24(u32 a, u32 b)
+{
+    return (a & 0xffffffu) * (b & 0xffffffu);      // the masks tell the compiler what it needs to pick the 24-bit form
+}
+// nothing is scheduled across this point (device): used to keep loads that feed the END of a loop body at its start
+MRT_HD void sched_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// index of the lowest set bit of a non-zero word (v_ffbl_b32)
+MRT_HD u32 lowest_bit(u32 x) { return (u32)__builtin_ctz(x | 0x80000000u); }
 
 // rot_y * (look * v), src/rt.rs:730-731, 782, 792, 798.  When both matrices equal the identity as
 // values (default instance direction) and no component of v is zero / non-finite the two products
@@ -247,24 +260,22 @@ struct Scn {
                          // read through the scalar cache into SGPRs (MRT_UNIFORM_SMEM)
     const float *G;      // the whole blob in global memory (the octree leaf lists are not staged when every mesh has a TBVH)
     const Params *P;
-    void *lq;            // this lane's leaf queue (device: an LDS column, entry e at lq[e * lq_stride]; x86 test build: unused)
-    u32 lq_stride;
+    void *wk;            // this lane's walk area (device: an LDS column, entry e at wk[e * wk_stride]; x86 test build: unused)
+    u32 wk_stride;
 };
 
-// The leaf queue of the closest-hit mesh walk: leaf words (count << 24 | first triangle) a lane has found and not tested yet.
-// Device: a per-lane LDS column behind the lane stash (slot-major like the stash: lane i always hits bank i); the x86 test
-// build keeps it in a local array.
-template <u32 Q>
-struct LeafQ {
+// The walk area of one lane: entries of one word each (device: a per-lane LDS column behind the lane stash, slot-major like
+// the stash, so lane i always hits bank i; the x86 test build keeps it in a local array).
+struct WalkMem {
 #if defined(__HIP_DEVICE_COMPILE__)
     lds_vfloat *b;
     u32 stride;
-    MRT_HD explicit LeafQ(const Scn &S) : b((lds_vfloat *)S.lq), stride(S.lq_stride) {}
+    MRT_HD explicit WalkMem(const Scn &S) : b((lds_vfloat *)S.wk), stride(S.wk_stride) {}
     MRT_HD void put(u32 e, u32 v) { b[e * stride] = u2f(v); }
     MRT_HD u32 get(u32 e) const { return f2u(b[e * stride]); }
 #else
-    u32 v[Q ? Q : 1u];
-    MRT_HD explicit LeafQ(const Scn &) {}
+    u32 v[kWalkCapMax];
+    MRT_HD explicit WalkMem(const Scn &) {}
     MRT_HD void put(u32 e, u32 x) { v[e] = x; }
     MRT_HD u32 get(u32 e) const { return v[e]; }
 #endif
@@ -417,9 +428,153 @@ MRT_HD bool mesh_isect_ref(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, f
     return any;
 }
 
-// Mesh arm of Renderer::intersect with the octree walk of intersect_bvh, src/rt.rs:707-723, 740-772.
-// The candidate list is consumed in the reference's order (leaf lists of hit leaves, concatenated,
-// consecutive duplicates dropped) without being materialised.
+// Mesh arm of Renderer::intersect, src/rt.rs:740-772 with the octree walk of intersect_bvh, src/rt.rs:707-723 -- answered from
+// the other side (mrt_scene.h): a triangle BVH finds the triangles the ray can hit (conservative culling), the exact triangle
+// test runs on those, and a hit triangle counts iff the reference's octree walk would have listed it (membership + parent
+// tables, exact box tests).  The candidate set, and with it the answer, does not depend on the order of the tests.
+
+// the conservative slab test of the triangle BVHs: box (c, h) in mesh coordinates against a ray given as inv = 1 / d (clamped),
+// ainv = |inv|, oinv = o * inv, qm = margin * |inv|:  t = c * inv - o * inv -+ (h * |inv| + mg * |inv|)
+struct TriCull { V3 inv, ainv, oinv, qm; };
+MRT_HD bool tri_cull_hit(const TriCull &R, float cx, float cy, float cz, float hx, float hy, float hz)
+{
+    const float px = fma_fast(cx, R.inv.x, -R.oinv.x), py = fma_fast(cy, R.inv.y, -R.oinv.y), pz = fma_fast(cz, R.inv.z, -R.oinv.z);
+    const float qx = fma_fast(hx, R.ainv.x, R.qm.x), qy = fma_fast(hy, R.ainv.y, R.qm.y), qz = fma_fast(hz, R.ainv.z, R.qm.z);
+    const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
+    const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
+    return !(tn > tf || tf < 0.0f);
+}
+
+// Meshes beyond the LDS (F_DEEP): 4-WIDE triangle BVH (mrt_scene.h) -- a visit decides four subtrees with one round of
+// independent 16-byte reads and only children whose box the ray hits are visited: a fifth of the dependent round trips of the
+// binary walk (5.5 / 7.8 / 8.9 visits per path segment on meshes of 1k / 5k / 20k triangles, where the binary walk makes ~30 /
+// ~45 / ~60), which is what counts when most nodes and all triangles come through L2.  It costs more VALU per visit (~125), so
+// meshes that fit the LDS keep the binary walk.  "While-while" with a per-lane node stack and a queue of postponed leaves,
+// both in the lane's walk area (Params.walk_cap entries; stack from entry 0 up, queue from the last entry down):
+//   box phase   visit a node = seven independent 16-byte reads + four slab tests; hit leaves go to the queue; of the hit
+//               internal children the first is visited next and the others become ONE stack entry ((index of the node's
+//               first child) << 4 | mask of children still to visit: internal children are consecutive nodes) -- so the stack
+//               is never deeper than the tree; when nothing internal was hit the next pending child of the top entry is taken,
+//               read at the START of the visit (next to the node: its latency is never on the chain).  The step is one basic
+//               block; the loop's only branch is its wave-uniform exit.  A visit needs four free entries.
+//   exact phase all queued triangles, one per lane per trip.
+// A closest-hit query walks until the tree is exhausted or the area is full; a shadow query (ANY) stops the box phase at the
+// first leaf: its first candidate ends it.  An area that the stack alone fills (a degenerate tree) is answered by the caller
+// through the reference's own walk: exact, only slow.  Returns 0 none, 1 hit, 2 overflow.
+template <bool ANY, u32 FEAT>
+MRT_HD int mesh_walk4(const Scn &S, u32 tb, const TriCull &R, u32 tri0, u32 root, V3 ro, V3 rd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
+{
+    const Params &P = *S.P;
+    const float *F = S.F;
+    const float *C = S.G;                                // membership tables and triangles: cold (F_DEEP implies F_COLD)
+    const float *CT = S.G;
+    const float *N0 = F + P.off_node;
+    const float *B0 = S.F + P.off_tbvh;
+    bool any = false;
+    i32 k0 = 0, k1 = 0;
+    u32 s0 = 0, s1 = 0;
+    float a0, a1;
+    WalkMem W(S);
+    const u32 cap = P.walk_cap;
+    u32 cur = tb;              // index of the node to visit, NO_NODE: none
+    u32 sp = 0u;               // stack entries W[0 .. sp)
+    for (;;) {
+        u32 nq = 0u;           // queued leaves W[cap - 1 .. cap - nq]
+        u32 probe_steps = 0; (void)probe_steps;
+        bool walking = cur != NO_NODE && sp + 4u <= cap;
+        while (walking) {
+            ++probe_steps;
+            MRT_COUNT(CT_TBVH_NODE);
+            const u32 noff = mul24(cur, B4_WORDS);               // (node indices are below 2^24: pack_scene)
+            const float *Nd = B0 + noff;
+            if (cur >= P.n_tbvh_hot) Nd = S.G + P.off_tbvh + noff;      // below the staged levels
+            const u32 top = W.get(sp ? sp - 1u : 0u);            // the entry a pop would take from (meaningless when sp == 0)
+            const F4 cx = ld4(Nd, B4_CX), cy = ld4(Nd, B4_CY), cz = ld4(Nd, B4_CZ), hx = ld4(Nd, B4_HX), hy = ld4(Nd, B4_HY), hz = ld4(Nd, B4_HZ);
+            const F4 cw = ld4(Nd, B4_CHILD);
+            sched_fence();                                       // all eight reads are issued here, whatever is scheduled below
+            const u32 w0 = f2u(cw.x), w1 = f2u(cw.y), w2 = f2u(cw.z), w3 = f2u(cw.w);
+            const bool h0 = tri_cull_hit(R, cx.x, cy.x, cz.x, hx.x, hy.x, hz.x) && w0 != 0u, h1 = tri_cull_hit(R, cx.y, cy.y, cz.y, hx.y, hy.y, hz.y) && w1 != 0u;
+            const bool h2 = tri_cull_hit(R, cx.z, cy.z, cz.z, hx.z, hy.z, hz.z) && w2 != 0u, h3 = tri_cull_hit(R, cx.w, cy.w, cz.w, hx.w, hy.w, hz.w) && w3 != 0u;
+            // hit internal children as a mask (internal children occupy the first slots and are consecutive nodes)
+            const u32 hm = ((h0 && (w0 >> 31)) ? 1u : 0u) | ((h1 && (w1 >> 31)) ? 2u : 0u) | ((h2 && (w2 >> 31)) ? 4u : 0u) | ((h3 && (w3 >> 31)) ? 8u : 0u);
+            const u32 c0 = w0 & ~B4_INTERNAL;                    // index of child 0 (only used when some internal child was hit)
+            const u32 from = hm ? ((c0 << 4) | hm) : top;        // entry the next node comes out of
+            const bool have = hm != 0u || sp != 0u;
+            const u32 k = lowest_bit(from & 15u);
+            const u32 rest = from & (from - 1u);                 // the entry without that child (its mask is non-zero whenever it is used)
+            cur = have ? (from >> 4) + k : NO_NODE;
+            const bool keep = (rest & 15u) != 0u;
+            // hm != 0: push `rest` when children remain; hm == 0: the top entry shrinks in place, or goes when it is spent
+            const u32 at = hm ? sp : (sp ? sp - 1u : 0u);
+            W.put(at, rest);                                     // (a spent or unused entry is rewritten harmlessly: W[at] is free or dead)
+            sp = hm ? sp + (keep ? 1u : 0u) : sp - ((sp != 0u && !keep) ? 1u : 0u);
+            // leaves: one store per child to the next free queue entry; it only counts when the pointer moves
+            W.put(cap - 1u - nq, w0); nq += (h0 && !(w0 >> 31)) ? 1u : 0u;
+            W.put(cap - 1u - nq, w1); nq += (h1 && !(w1 >> 31)) ? 1u : 0u;
+            W.put(cap - 1u - nq, w2); nq += (h2 && !(w2 >> 31)) ? 1u : 0u;
+            W.put(cap - 1u - nq, w3); nq += (h3 && !(w3 >> 31)) ? 1u : 0u;
+            walking = cur != NO_NODE && sp + nq + 4u <= cap && (!ANY || nq == 0u);
+        }
+        if (nq == 0u) {
+            MRT_PROBE_ROUND(probe_steps, 0u, 0u);
+            if (cur == NO_NODE) break;
+            MRT_COUNT(CT_WALK_OVERFLOW);                         // nodes left, nothing queued, no room
+            return 2;
+        }
+        MRT_COUNT(CT_WALK_ROUND);
+        u32 e = 0u, j = 0u, leaf = W.get(cap - 1u), probe_tris = 0; (void)probe_tris;
+        while (e < nq) {
+            const u32 id = (leaf & 0xffffffu) + j;
+            ++j; ++probe_tris;
+            if (j == (leaf >> 24)) { ++e; j = 0u; if (e < nq) leaf = W.get(cap - 1u - e); }
+            // (the exact half is written out here, `continue` by `continue`, as in the binary walks: the same statements behind
+            // a helper with early returns compiled into a slower loop, 3.10 against 3.33 Gsamples/s on the 967-triangle scene)
+            const float *T = CT + P.off_tri + (tri0 + id) * TRI_WORDS;
+            float t;
+            MRT_COUNT(CT_TBVH_TRI);
+            if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t)) continue;
+            MRT_COUNT(CT_TBVH_TRI_HIT);
+            // candidate iff some octree leaf listing the triangle is reached: every box from that leaf up to the root hit
+            const u32 head = ldu(C, P.off_memb + tri0 + id);
+            const u32 e0 = head & 0xffffffu, ne = head >> 24;
+            u32 sl = 0xffffffffu, sh = 0u;
+            bool cand = false;
+            for (u32 q = 0; q < ne; ++q) {
+                const u32 w = ldu(C, P.off_membe + e0 + q);
+                u32 n = root + (w >> MEMB_SLOT_BITS);
+                bool reached = true;
+                while (n != root) {
+                    MRT_COUNT(CT_MEMB_BOX);
+                    if (!box_isect(ld3(N0, n * NODE_WORDS + NODE_HALF), ro, m, add(pos, ld3(N0, n * NODE_WORDS + NODE_REL)), a0, a1)) { reached = false; break; }
+                    n = ldu(F, P.off_parent + n);
+                }
+                if (!reached) continue;
+                if (ANY) return 1;
+                const u32 slot = w & MEMB_SLOT_MASK;    // entries are in slot order
+                if (!cand) sl = slot;
+                sh = slot;
+                cand = true;
+            }
+            if (!cand) continue;
+            const i32 k = total_key(t);
+            if (!any) { any = true; t0 = t1 = t; i0 = i1 = (i32)id; k0 = k1 = k; s0 = sl; s1 = sh; continue; }
+            if (k < k0 || (k == k0 && sl < s0)) { k0 = k; s0 = sl; t0 = t; i0 = (i32)id; }      // min_by: first minimum, src/rt.rs:764
+            if (k > k1 || (k == k1 && sh > s1)) { k1 = k; s1 = sh; t1 = t; i1 = (i32)id; }      // max_by: last maximum, src/rt.rs:765
+        }
+        MRT_PROBE_ROUND(probe_steps, probe_tris, 0u);
+        if (cur == NO_NODE) break;
+    }
+    return any ? 1 : 0;
+}
+
+// Meshes in LDS walk a BINARY triangle BVH, threaded (stackless, depth-first, skip links), one 32-byte node per step: 27 VALU
+// per step, which is what these walks are bound by -- a wavefront pays the longest walk of its lanes (tests/emu/round_probe.cpp):
+//   closest-hit query, kernels with a walk area (F_COLD): EVERY leaf postponed -- the box walk runs until the tree is
+//     exhausted or the lane's queue of kLeafQueue leaves is full, then all queued triangles are tested, one per lane per trip
+//     (76 -> 46 box steps, 12 -> 11 triangle tests per loop iteration of the bench mesh against two-leaf rounds);
+//   otherwise ("while-while" with one postponed leaf): a lane walks boxes until it holds two leaves (or the end), then the
+//     wavefront runs the exact tests of both.  Shadow queries keep this form: their first candidate ends the walk.
+// The step is one basic block (next node, leaf bookkeeping and the done flag are selects); the loop's only branch is its exit.
 template <bool ANY, u32 FEAT>
 MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
 {
@@ -434,6 +589,33 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
     i32 k0 = 0, k1 = 0;
     MRT_COUNT(CT_MESH_CALL);
 
+    if constexpr (FEAT & F_DEEP) {
+        // ---- meshes beyond the LDS: the 4-wide table ----
+        const V3 ol = sub(ro, pos);
+        if (tb != NO_NODE && cull_ok(ol, dd) && fabs_(pos.x) < 1e6f && fabs_(pos.y) < 1e6f && fabs_(pos.z) < 1e6f) {
+            const float *N0 = F + P.off_node;
+            float a0, a1;
+            // a ray that misses the octree root has no candidates at all, src/rt.rs:745
+            if (!box_isect(ld3(N0, root * NODE_WORDS + NODE_HALF), ro, m, add(pos, ld3(N0, root * NODE_WORDS + NODE_REL)), a0, a1)) return false;
+            MRT_COUNT(CT_MESH_ROOT_HIT);
+            const CullRay CR = cull_ray(ol, rd);
+            TriCull R;
+            R.inv = CR.inv; R.ainv = CR.ainv;
+            {
+                const V3 c = ld3(M, MESH_BC), hh = ld3(M, MESH_BH);
+                const float big = fmax_(fmax_(fabs_(pos.x), fabs_(pos.y)), fabs_(pos.z)) + fmax_(fmax_(fabs_(c.x) + hh.x, fabs_(c.y) + hh.y), fabs_(c.z) + hh.z)
+                                  + fmax_(fmax_(fabs_(ol.x), fabs_(ol.y)), fabs_(ol.z));
+                const float mg = cull_margin(kMarginTri, sub(c, ol), hh, big);
+                R.oinv = hadam(ol, R.inv);
+                R.qm = muls(R.ainv, mg);
+            }
+            const int r = mesh_walk4<ANY, FEAT>(S, tb, R, tri0, root, ro, rd, m, pos, t0, i0, t1, i1);
+            if (r == 2) return mesh_isect_ref<ANY, FEAT>(S, mesh, ro, rd, m, pos, t0, i0, t1, i1);
+            return r != 0;
+        }
+        return mesh_isect_ref<ANY, FEAT>(S, mesh, ro, rd, m, pos, t0, i0, t1, i1);
+    }
+
     // ---- triangle BVH route (mrt_scene.h): the triangles the ray hits, then their candidacy in the reference's octree walk ----
     const V3 ol = sub(ro, pos);
     if (tb != NO_NODE && cull_ok(ol, dd) && fabs_(pos.x) < 1e6f && fabs_(pos.y) < 1e6f && fabs_(pos.z) < 1e6f) {
@@ -443,12 +625,11 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
         if (!box_isect(ld3(N0, root * NODE_WORDS + NODE_HALF), ro, m, add(pos, ld3(N0, root * NODE_WORDS + NODE_REL)), a0, a1)) return false;
         MRT_COUNT(CT_MESH_ROOT_HIT);
         const float *B0 = F + P.off_tbvh;
-        // one culling margin per ray, from the mesh bounds (the TBVH root)
+        // one culling margin per ray, from the mesh bounds
         const CullRay R = cull_ray(ol, rd);
         V3 oinv, qm;
         {
-            const F4 ra = ld4(B0, tb * BVH_WORDS), rb = ld4(B0, tb * BVH_WORDS + 4);      // (a root is always among the staged nodes)
-            const V3 c = v3(ra.x, ra.y, ra.z), hh = v3(ra.w, rb.x, rb.y);
+            const V3 c = ld3(M, MESH_BC), hh = ld3(M, MESH_BH);
             const float big = fmax_(fmax_(fabs_(pos.x), fabs_(pos.y)), fabs_(pos.z)) + fmax_(fmax_(fabs_(c.x) + hh.x, fabs_(c.y) + hh.y), fabs_(c.z) + hh.z)
                               + fmax_(fmax_(fabs_(ol.x), fabs_(ol.y)), fabs_(ol.z));
             const float mg = cull_margin(kMarginTri, sub(c, ol), hh, big);
@@ -457,30 +638,25 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
         }
         u32 s0 = 0, s1 = 0;
         u32 node = tb;
-        if constexpr (!ANY && leaf_queue_for(FEAT) != 0u) {
+        if constexpr (!ANY && has_walk_area(FEAT)) {
             // Closest-hit walk with EVERY leaf postponed: the box walk runs on until the tree is exhausted (or the lane's queue
             // of kQ leaves is full), then the exact tests of all queued leaves run together, one triangle per lane per trip.
             // A wavefront pays, per round, the longest box walk and the longest triangle list of its lanes: with two leaves
             // per round (below) that is 76 box steps + 12 triangle tests per loop iteration on the 967-triangle bench mesh,
             // with one round per walk 46 + 11 (tests/emu/round_probe.cpp).  Shadow queries keep the two-leaf rounds: their
             // first candidate ends the walk.  The candidate set, and with it the answer, is the same in any order.
-            constexpr u32 kQ = leaf_queue_for(FEAT);
-            LeafQ<kQ> q(S);
+            constexpr u32 kQ = kLeafQueue;
+            WalkMem q(S);
             for (;;) {
                 u32 nq = 0u;
                 u32 probe_steps = 0; (void)probe_steps;
                 bool walking = node != BVH_END;
                 while (walking) {
                     ++probe_steps;
-                    F4 na, nb;
-                    if constexpr (FEAT & F_DEEP) {
-                        if (node < P.n_tbvh_hot) { na = ld4(B0, node * BVH_WORDS); nb = ld4(B0, node * BVH_WORDS + 4); }
-                        else { const float *BG = S.G + P.off_tbvh; na = ld4(BG, node * BVH_WORDS); nb = ld4(BG, node * BVH_WORDS + 4); }
-                    } else { na = ld4(B0, node * BVH_WORDS); nb = ld4(B0, node * BVH_WORDS + 4); }
+                    const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
                     MRT_COUNT(CT_TBVH_NODE);
                     const u32 skip = f2u(nb.z);
-                    u32 leaf = f2u(nb.w), child = node + 1u;
-                    if constexpr (FEAT & F_DEEP) { child = leaf & ~BVH_INTERNAL; leaf = (leaf & BVH_INTERNAL) ? 0u : leaf; }
+                    const u32 leaf = f2u(nb.w), child = node + 1u;
                     const float px = fma_fast(na.x, R.inv.x, -oinv.x), py = fma_fast(na.y, R.inv.y, -oinv.y), pz = fma_fast(na.z, R.inv.z, -oinv.z);
                     const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);
                     const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
@@ -542,16 +718,10 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             bool walking = node != BVH_END;
             while (walking) {
                 ++probe_steps;
-                F4 na, nb;
-                if constexpr (FEAT & F_DEEP) {          // the top levels from LDS, the rest from global memory
-                    if (node < P.n_tbvh_hot) { na = ld4(B0, node * BVH_WORDS); nb = ld4(B0, node * BVH_WORDS + 4); }
-                    else { const float *BG = S.G + P.off_tbvh; na = ld4(BG, node * BVH_WORDS); nb = ld4(BG, node * BVH_WORDS + 4); }
-                } else { na = ld4(B0, node * BVH_WORDS); nb = ld4(B0, node * BVH_WORDS + 4); }
-                MRT_PROBE_TBVH_PART(node, f2u(B0[(tb + 1u) * BVH_WORDS + BVH_SKIP]));
+                const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
                 MRT_COUNT(CT_TBVH_NODE);
                 const u32 skip = f2u(nb.z);
-                u32 leaf = f2u(nb.w), child = node + 1u;
-                if constexpr (FEAT & F_DEEP) { child = leaf & ~BVH_INTERNAL; leaf = (leaf & BVH_INTERNAL) ? 0u : leaf; }
+                const u32 leaf = f2u(nb.w), child = node + 1u;
                 // t = c * inv - o * inv -+ (h * |inv| + mg * |inv|)
                 const float px = fma_fast(na.x, R.inv.x, -oinv.x), py = fma_fast(na.y, R.inv.y, -oinv.y), pz = fma_fast(na.z, R.inv.z, -oinv.z);
                 const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);

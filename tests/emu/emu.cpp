@@ -3,6 +3,7 @@
 // can check the kernel's per-lane logic and the packed scene layout against the CPU oracle
 // without a GPU.  Nothing in the product loads this library; libmrt_hip.so has no CPU path.
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -17,6 +18,15 @@
 using namespace mrt;
 
 static thread_local std::string g_err;
+
+// entries of a lane's walk area (mrt_trace.h): MRT_EMU_WALK_CAP in the environment, so that tests can shrink it until walks
+// flush early and overflow into the reference's walk
+static uint32_t walk_cap()
+{
+    const char *v = getenv("MRT_EMU_WALK_CAP");
+    const int c = v ? atoi(v) : (int)kWalkCapDefault;
+    return c < 4 ? 4u : (c > (int)kWalkCapMax ? kWalkCapMax : (uint32_t)c);
+}
 
 extern "C" {
 
@@ -63,15 +73,16 @@ int emu_render_deep(const mrt_render_desc *d, uint64_t seed, uint32_t sample_bas
                     uint32_t threads, float *accum, uint64_t *segments, uint32_t deep_nodes)
 {
     Packed pk;
-    PackOpts po;
-    const bool warm_only = deep_nodes == 0xffffffffu;      // F_COLD without F_DEEP: the queued closest-hit walk on the depth-first table
+    const bool warm_only = deep_nodes == 0xffffffffu;      // F_COLD without F_DEEP: the queued closest-hit walk on the binary table
     if (warm_only) deep_nodes = 0;
-    po.tbvh_level_order = deep_nodes != 0;
+    PackOpts po;
+    po.tbvh_wide = deep_nodes != 0;
     const int rc = pack_scene(d, pk, g_err, po);
     if (rc) return rc;
-    if (deep_nodes && !pk.tbvh_level_order) { g_err = "no triangle BVH to order"; return -100; }
+    if (deep_nodes && !pk.tbvh_wide) { g_err = "no triangle BVH to widen"; return -100; }
     Params P = pk.P;
     P.n_tbvh_hot = deep_nodes;
+    if (deep_nodes) P.walk_cap = walk_cap();
     P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
     P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32);
     P.n_samples = n_samples; P.sample_base = sample_base; P.k_split = 1; P.accum = accum;
@@ -177,6 +188,7 @@ void emu_math(int op, const float *a, const float *b, float *out, size_t n)
 
 // Mesh arm of Renderer::intersect for n rays against renderer 0 (a mesh), through the TBVH route and through the reference's
 // octree walk (forced by dd = NaN, which only steers the route).  out[i*10..]: hit, t0 bits, i0, t1 bits, i1 for each route.
+// A third route walks the 4-wide table of the same mesh (F_DEEP lane code).
 // Returns the number of rays on which the routes differ (ANY queries included), or < 0.
 int emu_mesh_probe(const mrt_render_desc *d, uint32_t n, const float *orig, const float *dir, uint32_t *out, uint32_t *stats /*[2]*/)
 {
@@ -192,25 +204,42 @@ int emu_mesh_probe(const mrt_render_desc *d, uint32_t n, const float *orig, cons
     uint32_t hits = 0, with_tbvh = 0;
     const float *M = S.F + P.off_mesh;
     with_tbvh = ldu(M, MESH_TBVH) != NO_NODE;
+    // the same mesh with the 4-wide table (what the F_DEEP kernels walk): a third route through the same exact tests
+    Packed pkw;
+    PackOpts po; po.tbvh_wide = true;
+    if (pack_scene(d, pkw, g_err, po)) return -101;
+    Params Pw = pkw.P;
+    Pw.n_tbvh_hot = 1; Pw.walk_cap = walk_cap();
+    Scn Sw;
+    Sw.F = reinterpret_cast<const float *>(pkw.blob.data());
+    Sw.U = Sw.F; Sw.G = Sw.F; Sw.P = &Pw;
     for (uint32_t i = 0; i < n; ++i) {
         const V3 o = v3(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]), dr = v3(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
         const RayPre ray = ray_pre<F_ALL>(o, dr);
-        uint32_t r[2][5];
-        bool anyq[2];
-        for (int route = 0; route < 2; ++route) {
-            const float *I = S.F + P.off_inst;
+        uint32_t r[3][5];
+        bool anyq[3];
+        for (int route = 0; route < 3; ++route) {
+            const Scn &SS = route == 2 ? Sw : S;
+            const float *I = SS.F + SS.P->off_inst;
             const F4 ia = ld4(I, 0);
             const V3 pos = v3(ia.x, ia.y, ia.z);
-            const float dd = route == 0 ? ray.dd : __builtin_nanf("");
+            const float dd = route != 1 ? ray.dd : __builtin_nanf("");
             float t0 = 0, t1 = 0; i32 i0 = -1, i1 = -1;
             const V3 ro = add(pos, sub(ray.o, pos));
-            const bool h = mesh_isect<false, F_ALL>(S, 0, ro, ray.d, dd, ray.m, pos, t0, i0, t1, i1);
             float u0 = 0, u1 = 0; i32 j0 = -1, j1 = -1;
-            anyq[route] = mesh_isect<true, F_ALL>(S, 0, ro, ray.d, dd, ray.m, pos, u0, j0, u1, j1);
+            bool h;
+            if (route == 2) {
+                h = mesh_isect<false, F_ALL | F_COLD | F_DEEP>(SS, 0, ro, ray.d, dd, ray.m, pos, t0, i0, t1, i1);
+                anyq[route] = mesh_isect<true, F_ALL | F_COLD | F_DEEP>(SS, 0, ro, ray.d, dd, ray.m, pos, u0, j0, u1, j1);
+            } else {
+                h = mesh_isect<false, F_ALL>(SS, 0, ro, ray.d, dd, ray.m, pos, t0, i0, t1, i1);
+                anyq[route] = mesh_isect<true, F_ALL>(SS, 0, ro, ray.d, dd, ray.m, pos, u0, j0, u1, j1);
+            }
             r[route][0] = h; r[route][1] = h ? f2u(t0) : 0; r[route][2] = h ? (u32)i0 : 0; r[route][3] = h ? f2u(t1) : 0; r[route][4] = h ? (u32)i1 : 0;
         }
         if (r[0][0]) ++hits;
-        if (memcmp(r[0], r[1], sizeof r[0]) != 0 || anyq[0] != anyq[1] || anyq[0] != (bool)r[0][0]) ++bad;
+        // (triangle ids are positions in the table's leaf order, which both tables share: they come from one binary tree)
+        if (memcmp(r[0], r[1], sizeof r[0]) != 0 || memcmp(r[0], r[2], sizeof r[0]) != 0 || anyq[0] != anyq[1] || anyq[0] != anyq[2] || anyq[0] != (bool)r[0][0]) ++bad;
         if (out) { memcpy(out + (size_t)i * 10, r[0], sizeof r[0]); memcpy(out + (size_t)i * 10 + 5, r[1], sizeof r[1]); }
     }
     if (stats) { stats[0] = hits; stats[1] = with_tbvh; }

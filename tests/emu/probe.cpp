@@ -4,6 +4,7 @@
 // wavefront had to execute a phase.
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -17,7 +18,6 @@ static thread_local std::vector<uint32_t> *g_work_any = nullptr;   // the same f
 static thread_local bool g_in_any = false;
 static thread_local bool g_right = false;                           // walking the right half of a triangle BVH
 static thread_local std::vector<uint32_t> *g_work_r = nullptr, *g_work_any_r = nullptr;   // triangle-BVH work in right halves
-#define MRT_PROBE_TBVH_PART(node, right0) (g_right = (node) >= (right0))
 #define MRT_COUNT(counter) do { ++g_cnt[counter]; if ((counter) == 0) g_in_any = false; if ((counter) == 10) g_in_any = true; \
     if (g_work && !g_work->empty()) { std::vector<uint32_t> *w_ = (g_in_any && g_work_any) ? g_work_any : g_work; \
         if ((counter) == 2 || (counter) == 6) w_->back() += 1; else if ((counter) == 1 || (counter) == 7) w_->back() += 3; \
@@ -72,6 +72,7 @@ extern "C" int probe_counts(const mrt_render_desc *d, uint64_t seed, uint32_t n_
     P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.n_samples = n_samples; P.sample_base = 0; P.k_split = 1;
     std::vector<float> frame((size_t)pk.nw * pk.nh * 3, 0.0f); P.accum = frame.data();
     Scn S; S.F = reinterpret_cast<const float *>(pk.blob.data()); S.U = S.F; S.G = S.F; S.P = &P;
+    if (const char *v = getenv("MRT_EMU_WALK_CAP")) { const int c = atoi(v); if (c >= 4 && c <= (int)kWalkCapMax) P.walk_cap = (u32)c; }
     memset(g_cnt, 0, sizeof g_cnt);
     uint64_t seg = 0;
     for (uint32_t y = 0; y < pk.nh; ++y)

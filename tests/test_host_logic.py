@@ -439,20 +439,21 @@ def test_launch_plan_staging_levels_and_shapes(monkeypatch):
         p = plan(d)
         assert (p["staging"], p["block_threads"], p["kernel_features"], p["small_plain_grid"]) == ("all", 256, feat, 1), p
         assert p["staged_bytes"] == p["scene_bytes"] < 6 * 1024 and 8 * p["lds_bytes"] <= LDS
-    # the 967-triangle mesh scene: warm (membership tables + texels out), one 1024-thread workgroup with stash and leaf queues
+    # the 967-triangle mesh scene: warm (membership tables + texels out), one 1024-thread workgroup with stash and walk areas
     p = plan(scenes.mesh_scene())
     assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("warm", 1024, 15 | 64), p
+    assert p["walk_cap"] == 8                                       # the leaf queue of the binary walk
     assert p["staged_bytes"] < p["scene_bytes"] and p["lds_bytes"] == p["staged_bytes"] + 1024 * 4 * (10 + 8) <= LDS
-    assert p["tbvh_hot_nodes"] == p["tbvh_nodes"] > 1000
+    assert p["tbvh_hot_nodes"] == p["tbvh_nodes"] > 1000            # binary nodes
     # the Minecraft-shaped scene: warm, 256-thread workgroups (6-wave kernel: six of them per CU), texels out of LDS
     p = plan(scenes.minecraft_like())
     assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("warm", 256, 29 | 64), p
     assert p["scene_bytes"] - p["staged_bytes"] > 70 * 1024 and 6 * p["lds_bytes"] <= LDS < 7 * p["lds_bytes"]
-    # meshes beyond the LDS: deep -- level-ordered triangle BVH, as many top nodes as fit, triangles out
+    # meshes beyond the LDS: deep -- 4-wide triangle BVH in level order, as many top nodes as fit, triangles out
     for n in (5120, 20480):
         p = plan(scenes.mesh_scene(res=(64, 36), n_tris=n))
         assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("deep", 1024, 15 | 64 | 128), p
-        assert 3000 < p["tbvh_hot_nodes"] < p["tbvh_nodes"] and LDS - 4096 < p["lds_bytes"] <= LDS
+        assert 500 < p["tbvh_hot_nodes"] < p["tbvh_nodes"] and LDS - 4096 < p["lds_bytes"] <= LDS and p["walk_cap"] == 12
     # 1000 instances, no texels: nothing to leave out, one copy for a 1024-thread workgroup
     p = plan(scenes.instance_grid())
     assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("all", 1024, 8 | 16), p
