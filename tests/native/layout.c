@@ -28,6 +28,6 @@ int main(void)
     S(mrt_stats); F(mrt_stats, kernel_ms); F(mrt_stats, gather_ms); F(mrt_stats, samples); F(mrt_stats, segments); F(mrt_stats, launches); F(mrt_stats, lds_bytes);
     F(mrt_stats, block_threads); F(mrt_stats, scene_bytes); F(mrt_stats, k_split); F(mrt_stats, deferred); F(mrt_stats, img_ms); F(mrt_stats, reduce_ms); F(mrt_stats, kernel_features); F(mrt_stats, scene_in_lds);
     S(mrt_plan); F(mrt_plan, staging); F(mrt_plan, block_threads); F(mrt_plan, lds_bytes); F(mrt_plan, staged_bytes); F(mrt_plan, scene_bytes);
-    F(mrt_plan, kernel_features); F(mrt_plan, tbvh_nodes); F(mrt_plan, tbvh_hot_nodes); F(mrt_plan, small_plain_grid); F(mrt_plan, reserved);
+    F(mrt_plan, kernel_features); F(mrt_plan, tbvh_nodes); F(mrt_plan, tbvh_hot_nodes); F(mrt_plan, small_plain_grid); F(mrt_plan, walk_cap); F(mrt_plan, reserved);
     return 0;
 }
