@@ -253,7 +253,7 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
     //   wavefront, its own 5.5 KB of LDS -- remain as a forced shape for the tests);
     //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves.
     // Mesh kernels of the warm and deep levels own a per-lane walk area (Params.walk_cap entries, mrt_trace.h): the leaf queue
-    // of the binary walk (8 entries, warm), or node stack + leaf queue of the 4-wide walk (12 entries, deep: the scene is
+    // of the binary walk (8 entries, warm), or node stack + leaf queue of the 4-wide walk (16 entries, deep: the scene is
     // packed again with 4-wide triangle BVHs).
     // Environment (experiments, tests; read here, once): MRT_COLD=0/1 forbids / forces the warm level, MRT_DEEP_NODES=n forces
     // the deep level with n staged nodes, MRT_SCENE_IN_L2 forces none, MRT_BLOCK_THREADS forces a workgroup size, MRT_WALK_CAP

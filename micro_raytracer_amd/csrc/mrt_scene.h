@@ -102,7 +102,7 @@ enum : u32 { NODE_HALF = 0, NODE_REL = 3, NODE_FIRST = 6, NODE_COUNT = 7 };
 // the first Params.n_tbvh_hot nodes are staged, the rest is read from global memory.
 constexpr u32 B4_WORDS = 28;
 constexpr u32 B4_INTERNAL = 0x80000000u;
-constexpr u32 kWalkCapMin = 8u, kWalkCapMax = 16u, kWalkCapDefault = 12u;      // entries of a lane's walk area (Params.walk_cap)
+constexpr u32 kWalkCapMin = 8u, kWalkCapMax = 16u, kWalkCapDefault = 16u;      // entries of a lane's walk area (Params.walk_cap)
 enum : u32 { B4_CX = 0, B4_CY = 4, B4_CZ = 8, B4_HX = 12, B4_HY = 16, B4_HZ = 20, B4_CHILD = 24 };
 constexpr u32 BVH_WORDS = 8;
 constexpr u32 MEMB_SLOT_BITS = 22u, MEMB_SLOT_MASK = (1u << MEMB_SLOT_BITS) - 1u;

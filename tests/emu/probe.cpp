@@ -66,8 +66,11 @@ extern "C" int probe_divergence(const mrt_render_desc *d, uint64_t seed, uint32_
 extern "C" int probe_counts(const mrt_render_desc *d, uint64_t seed, uint32_t n_samples, uint64_t *counts /*[CT_COUNT]*/, uint64_t *segments)
 {
     Packed pk; std::string err;
-    if (pack_scene(d, pk, err)) return -1;
+    const bool deep = getenv("MRT_EMU_DEEP") != nullptr;           // the 4-wide walk of the F_DEEP kernels (one staged node)
+    PackOpts po; po.tbvh_wide = deep;
+    if (pack_scene(d, pk, err, po)) return -1;
     Params P = pk.P;
+    if (deep) P.n_tbvh_hot = 1;
     P.local_rows = pk.nh; P.shard_index = 0; P.shard_count = 1; P.shard_rows = 8;
     P.seed_lo = (u32)seed; P.seed_hi = (u32)(seed >> 32); P.n_samples = n_samples; P.sample_base = 0; P.k_split = 1;
     std::vector<float> frame((size_t)pk.nw * pk.nh * 3, 0.0f); P.accum = frame.data();
@@ -79,7 +82,8 @@ extern "C" int probe_counts(const mrt_render_desc *d, uint64_t seed, uint32_t n_
         for (uint32_t x = 0; x < pk.nw; ++x) {
             u32 sg = 0; RegStash st;
             LaneJob job; job.k = 0; job.word = (y * pk.nw + x) * 3u;
-            if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg);
+            if (deep) { if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH | F_COLD | F_DEEP>(S, st, x, y, job, sg); else render_pixel<F_ALL | F_COLD | F_DEEP>(S, st, x, y, job, sg); }
+            else if (pk.features & F_BVH) render_pixel<F_ALL | F_BVH>(S, st, x, y, job, sg); else render_pixel<F_ALL>(S, st, x, y, job, sg);
             seg += sg;
         }
     for (u32 c = 0; c < CT_COUNT; ++c) counts[c] = g_cnt[c];
