@@ -158,6 +158,12 @@ typedef struct mrt_opts {
                                         one atomic per wavefront, a read-back when mrt_get_stats is called */
 #define MRT_FLAG_NO_EVENT_TIMING 2u  /* no HIP events around the kernels (mrt_stats.kernel_ms / reduce_ms stay 0): what a caller that
                                         runs one sample per call (src/cli.rs:162-170) and never asks for stats wants */
+#define MRT_FLAG_NO_LOOKAHEAD 8u     /* one-sample mrt_execute calls always run their own one-sample launch.  Default: a context that
+                                        sees one-sample calls arrive back to back traces the NEXT samples ahead on a second stream
+                                        (2, 4, ... 32 per launch, each into a plane of its own) and a call only folds its sample into
+                                        the accumulator and waits for that: same samples, added in the same order -- bit for bit the
+                                        plain loop -- at the rate of batched launches; MRT_LOOKAHEAD=0 in the environment switches it
+                                        off too, MRT_LOOKAHEAD=n sets the samples per launch */
 #define MRT_FLAG_DEFER 4u            /* mrt_execute only books its samples; they are traced, batched, when 1024 are booked or when
                                         the accumulator is observed or replaced (mrt_accum*, mrt_img*, mrt_set_accum*, mrt_get_stats,
                                         mrt_bind_accum).  Same samples, same image as eager execution (sums re-associated like any

@@ -15,7 +15,7 @@ LIGHT_POINT, LIGHT_DIR = 0, 1
 KIND_IDS = {"sphere": KIND_SPHERE, "plane": KIND_PLANE, "box": KIND_BOX, "triangle": KIND_TRIANGLE, "mesh": KIND_MESH}
 
 MRT_OK, MRT_ERR_ARG, MRT_ERR_SCENE, MRT_ERR_DEVICE, MRT_ERR_LIMIT, MRT_ERR_STATE = 0, -1, -2, -3, -4, -5
-FLAG_COUNT_SEGMENTS, FLAG_NO_EVENT_TIMING, FLAG_DEFER = 1, 2, 4
+FLAG_COUNT_SEGMENTS, FLAG_NO_EVENT_TIMING, FLAG_DEFER, FLAG_NO_LOOKAHEAD = 1, 2, 4, 8
 
 
 class Camera(C.Structure):

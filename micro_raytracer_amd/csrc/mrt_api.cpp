@@ -144,6 +144,17 @@ struct mrt_ctx {
     size_t knob_partial_budget = 0;               // MRT_PARTIAL_LIMIT_BYTES (0: kPartialBudgetBytes)
     bool knob_partial_fail = false;               // MRT_PARTIAL_FAIL_ALLOC: the chunk-plane allocation asks for an impossible size
     u32 pending = 0;                              // samples requested by deferred mrt_execute calls and not traced yet
+    // Look-ahead of the eager per-call path (the reference's callers run one Sampler::execute per sample, src/cli.rs:162-170):
+    // see run_lookahead.  Two sets of per-sample planes [n][padded_rows][nw][3]; set i holds samples [la_base[i], la_base[i] + la_n[i]).
+    bool la_enabled = false;                      // eager single-device context without MRT_FLAG_NO_LOOKAHEAD / MRT_LOOKAHEAD=0
+    u32 la_max = 32;                              // samples per look-ahead launch at most (MRT_LOOKAHEAD=n)
+    u32 la_streak = 0;                            // consecutive one-sample calls so far
+    hipStream_t la_stream = nullptr;              // the look-ahead launches; the folds run on `stream`
+    float *d_la[2] = {nullptr, nullptr};
+    size_t la_floats[2] = {0, 0};
+    u32 la_base[2] = {0, 0}, la_n[2] = {0, 0};
+    hipEvent_t la_ev0[2] = {nullptr, nullptr}, la_ev1[2] = {nullptr, nullptr};   // around set i's trace launch, on la_stream
+    u32 *d_la_counter = nullptr;                  // tile counter of persistent look-ahead launches (the eager launches keep their own)
     Packed pk;
     Params P;
     u32 *d_blob = nullptr;
@@ -195,7 +206,10 @@ void free_ctx(mrt_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->d_rowmap) (void)hipFree(c->d_rowmap);
-    void *ptrs[] = {c->d_blob, c->d_accum_own, c->d_partial, c->d_segments, c->d_full, c->d_ss, c->d_out, c->d_tmp, c->d_vl, c->d_vc, c->d_hl, c->d_hc, c->d_vw, c->d_hw};
+    if (c->la_stream) { (void)hipStreamSynchronize(c->la_stream); (void)hipStreamDestroy(c->la_stream); }
+    for (int i = 0; i < 2; ++i) { if (c->la_ev0[i]) (void)hipEventDestroy(c->la_ev0[i]); if (c->la_ev1[i]) (void)hipEventDestroy(c->la_ev1[i]); }
+    void *ptrs[] = {c->d_blob, c->d_accum_own, c->d_partial, c->d_segments, c->d_full, c->d_ss, c->d_out, c->d_tmp, c->d_vl, c->d_vc, c->d_hl, c->d_hc, c->d_vw, c->d_hw,
+                    c->d_la[0], c->d_la[1], c->d_la_counter};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -441,6 +455,13 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if (const char *f = getenv("MRT_MAX_CHUNKS")) { const int v = atoi(f); if (v > 0) c->knob_max_chunks = (u32)v; }                   // tests
     if (const char *f = getenv("MRT_PARTIAL_LIMIT_BYTES")) c->knob_partial_budget = (size_t)strtoull(f, nullptr, 10);                  // tests
     c->knob_partial_fail = getenv("MRT_PARTIAL_FAIL_ALLOC") != nullptr;                                                                // tests
+    c->la_enabled = !c->defer && (opts->flags & MRT_FLAG_NO_LOOKAHEAD) == 0;
+    if (const char *f = getenv("MRT_LOOKAHEAD")) { const int v = atoi(f); if (v <= 1) c->la_enabled = false; else c->la_max = v > 64 ? 64u : (u32)v; }
+    {   // both plane sets together stay below 4 GiB (32 samples of a 1080p frame: 2 x 0.8 GB; a 4K frame gets 20 per launch)
+        const size_t plane_bytes = (size_t)c->padded_rows * nw * 3 * sizeof(float);
+        const size_t fit = plane_bytes ? ((size_t)2u << 30) / plane_bytes : 0;
+        if (fit < 2) c->la_enabled = false; else if (fit < c->la_max) c->la_max = (u32)fit;
+    }
     ok();
     return c;
 }
@@ -710,10 +731,115 @@ static int exec_group(mrt_ctx *g, uint32_t n_samples)
     return MRT_OK;
 }
 
+// ---- look-ahead of the eager per-call path -----------------------------------------------------------------------------------
+// The reference's callers run ONE Sampler::execute per sample and wait for it (src/cli.rs:162-170, src/http.rs:141-144).  A
+// one-sample launch cannot regenerate paths inside a lane (a wavefront lasts as long as its longest path: lane utilisation
+// 0.65 against 0.70, 0.36 ms per 1080p pass against 0.25 inside a batched launch), and the image is a pure function of (scene,
+// seed, sample index) -- so a context that sees one-sample calls arrive back to back traces AHEAD: samples [k, k + n) in one
+// launch on a second stream, every sample into a plane of its own (chunks of one sample, Params.chunk_shift = 0), and each call
+// only folds its sample's plane into the accumulator (reduce_chunks, 0.02 ms) and waits for that.  The accumulator holds
+// exactly the samples the caller has asked for at every return, added one by one in index order -- bit for bit what the plain
+// per-call loop leaves there -- so observing it (mrt_accum, mrt_img, a bound or handed-out pointer) needs no special case.  Two
+// plane sets: while one is folded call by call, the next launch already runs.  It starts at the third consecutive
+// one-sample call with two samples per launch and doubles up to la_max (32), so a caller that stops early wastes at most about
+// the work it has used; any other call (n != 1, reset, set_accum) drops what was traced ahead.
+static void la_drop(mrt_ctx *c)
+{
+    if (c->la_stream && (c->la_n[0] || c->la_n[1])) (void)hipStreamSynchronize(c->la_stream);
+    c->la_n[0] = c->la_n[1] = 0;
+    c->la_streak = 0;
+}
+
+// launch the trace of samples [base, base + n) into plane set i (asynchronous, on la_stream)
+static int la_launch(mrt_ctx *c, int i, u32 base, u32 n)
+{
+    const size_t plane = (size_t)c->padded_rows * c->pk.nw * 3;
+    if (!c->la_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->la_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) { HIP_TRY(hipEventCreate(&c->la_ev0[k])); HIP_TRY(hipEventCreate(&c->la_ev1[k])); }
+        HIP_TRY(hipMalloc((void **)&c->d_la_counter, sizeof(u32)));
+    }
+    if (plane * n > c->la_floats[i]) {
+        if (c->d_la[i]) { (void)hipFree(c->d_la[i]); c->d_la[i] = nullptr; c->la_floats[i] = 0; }
+        if (!hip_tolerated(hipMalloc((void **)&c->d_la[i], plane * n * sizeof(float)))) { c->d_la[i] = nullptr; return MRT_ERR_LIMIT; }     // the caller falls back
+        c->la_floats[i] = plane * n;
+    }
+    Params P = c->P;
+    P.n_samples = n; P.sample_base = base; P.k_split = 1u; P.chunk_shift = 0u; P.to_planes = 1u;
+    P.partial = c->d_la[i]; P.partial_stride = plane;
+    P.count_segments = 0u;
+    // small scenes: the plain grid (their persistent grid fills every wave slot of the chip and would keep the folds out until
+    // the launch has ended); larger ones leave slots free and keep their persistent workgroups, with a tile counter of their own
+    P.persist_grid = c->small_plain_grid ? 0u : c->persist_grid;
+    P.tile_counter = c->d_la_counter;
+    if (c->block_threads > 64u && P.persist_grid) HIP_TRY(hipMemsetAsync(c->d_la_counter, 0, sizeof(u32), c->la_stream));
+    HIP_TRY(hipEventRecord(c->la_ev0[i], c->la_stream));
+    HIP_TRY(launch_pt(P, c->block_threads, c->scene_in_lds, c->pk.features, c->la_stream));
+    HIP_TRY(hipEventRecord(c->la_ev1[i], c->la_stream));
+    c->la_base[i] = base; c->la_n[i] = n;
+    return MRT_OK;
+}
+
+// one eager one-sample call served from the look-ahead planes; returns MRT_ERR_LIMIT when the planes cannot be had (the caller
+// then runs the plain launch)
+static int run_lookahead(mrt_ctx *c)
+{
+    int rc = set_device(c);
+    if (rc) return rc;
+    const u32 k = c->count;
+    int s = -1;
+    for (int i = 0; i < 2; ++i) if (c->la_n[i] && k >= c->la_base[i] && k < c->la_base[i] + c->la_n[i]) s = i;
+    if (s < 0) {
+        // nothing traced ahead for this sample (first use, or what was ahead has been dropped): start both sets
+        la_drop(c);
+        c->la_streak = 2;
+        const u32 n0 = 2u < c->la_max ? 2u : c->la_max;
+        if ((rc = la_launch(c, 0, k, n0))) return rc;
+        const u32 n1 = 2u * n0 < c->la_max ? 2u * n0 : c->la_max;
+        if ((rc = la_launch(c, 1, k + n0, n1))) { (void)hipStreamSynchronize(c->la_stream); c->la_n[0] = c->la_n[1] = 0; return rc; }
+        s = 0;
+    }
+    const size_t plane = (size_t)c->padded_rows * c->pk.nw * 3;
+    const size_t words = (size_t)c->local_rows * c->pk.nw * 3;
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->la_ev1[s], 0));
+    HIP_TRY(launch_reduce_chunks(c->d_accum, c->d_la[s] + (size_t)(k - c->la_base[s]) * plane, words, plane, 1u, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                // the fold has run, so the set's launch has ended too
+    c->count += 1u;
+    c->stats.kernel_ms = 0; c->stats.reduce_ms = 0; c->stats.gather_ms = 0; c->stats.segments = 0;
+    c->stats_pending = false; c->ev_used = 0;
+    c->stats.launches = 1u; c->stats.k_split = 1u;
+    c->stats.samples = (uint64_t)c->local_rows * c->pk.nw;
+    c->stats.block_threads = c->block_threads;
+    if (c->event_timing) {
+        float ms = 0;
+        if (hip_tolerated(hipEventElapsedTime(&ms, c->la_ev0[s], c->la_ev1[s]))) c->stats.kernel_ms = (double)ms / (double)c->la_n[s];   // this sample's share of its launch
+    }
+    if (k + 1u == c->la_base[s] + c->la_n[s]) {
+        // the set is spent (its last plane has been folded): the next launch goes into it, behind the other set's, twice as long
+        const int o = 1 - s;
+        const u32 nb = c->la_base[o] + c->la_n[o];
+        const u32 nn = 2u * c->la_n[o] < c->la_max ? 2u * c->la_n[o] : c->la_max;
+        c->la_n[s] = 0;
+        if (c->la_n[o] && (unsigned long long)nb + nn <= 0xffffffffull) (void)la_launch(c, s, nb, nn);      // (a failure here only means a later call starts over)
+    }
+    return MRT_OK;
+}
+
 static int run_samples(mrt_ctx *c, uint32_t n_samples)
 {
     int rc;
     if (!c->subs.empty()) return exec_group(c, n_samples);
+    if (c->la_enabled && n_samples == 1u && c->local_rows) {
+        if (c->la_streak >= 2u) {
+            rc = run_lookahead(c);
+            if (rc != MRT_ERR_LIMIT) return rc;
+            c->la_enabled = false;                       // no memory for the planes: the plain per-call launch from here on
+        } else {
+            ++c->la_streak;
+        }
+    } else if (c->la_n[0] || c->la_n[1] || c->la_streak) {
+        la_drop(c);
+    }
     if ((rc = exec_launch(c, n_samples))) return rc;
     return exec_finish(c, n_samples);
 }
@@ -845,6 +971,7 @@ int mrt_set_accum_device(mrt_ctx *c, const void *dev_rgb, uint32_t count)
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = settle(c))) return rc;
+    la_drop(c);                                   // the sample count changes under what was traced ahead
     const size_t bytes = (size_t)c->pk.nw * c->pk.nh * 3 * sizeof(float);
     if (!c->subs.empty()) return fail(MRT_ERR_STATE, "mrt_set_accum_device: use mrt_set_accum on a multi-device context");
     if (c->shard_count == 1) {
@@ -865,6 +992,7 @@ int mrt_set_accum(mrt_ctx *c, const float *rgb, uint32_t count)
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = settle(c))) return rc;
+    la_drop(c);
     const size_t row_bytes = (size_t)c->pk.nw * 3 * sizeof(float);
     if (!c->subs.empty()) {
         HIP_TRY(hipMemcpy(c->d_full, rgb, row_bytes * c->pk.nh, hipMemcpyHostToDevice));
@@ -894,6 +1022,7 @@ int mrt_reset(mrt_ctx *c)
     c->pending = 0;                           // booked samples of a deferred context are dropped with everything else
     int rc = set_device(c);
     if (rc) return rc;
+    la_drop(c);
     if (!c->subs.empty()) {
         for (mrt_ctx *s : c->subs) if ((rc = mrt_reset(s))) return rc;
         HIP_TRY(hipSetDevice(c->device));

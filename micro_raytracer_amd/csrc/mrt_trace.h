@@ -1145,7 +1145,6 @@ template <class St> MRT_HD V3 st_get3(const St &st, u32 slot) { return v3(st.get
 // the pixel's accumulator in chunk order.  A lane owns every k_split-th chunk of a launch (k_split = 1: all of them,
 // added straight to the accumulator; k_split > 1: chunk sums go to `partial` and reduce_chunks adds them in order),
 // so small frames can be spread over more wavefronts with bit-identical results.
-constexpr u32 kChunk = 16;
 
 struct LaneJob {
     u32 k;                 // this lane's chunk phase, 0 <= k < P.k_split
@@ -1165,9 +1164,10 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     const u32 pix_key = mix32(pixel + P.seed_lo) ^ P.seed_hi;      // path_key = mix32(pix_key + sample * kGold)
     const V3 sky_init = v3(P.sky_init[0], P.sky_init[1], P.sky_init[2]);
     const u32 s_base = P.sample_base, s_stop = P.sample_base + P.n_samples;
-    const u32 g0 = s_base / kChunk;
-    const u32 n_chunks = (s_stop - 1u) / kChunk - g0 + 1u;          // n_samples > 0
-    const bool direct = P.k_split == 1u;
+    const u32 csh = P.chunk_shift;                                  // chunks of 1 << csh samples (4: kChunk; 0: look-ahead launches)
+    const u32 g0 = s_base >> csh;
+    const u32 n_chunks = ((s_stop - 1u) >> csh) - g0 + 1u;          // n_samples > 0
+    const bool direct = P.k_split == 1u && P.to_planes == 0u;
     if (direct) st_put3(st, ST_ACC, v3(P.accum[job.word], P.accum[job.word + 1u], P.accum[job.word + 2u]));
     st_put3(st, ST_FOCUS, pixel_focus(P, (float)x, (float)y));
 
@@ -1175,10 +1175,10 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     st.put(ST_PIXKEY, u2f(pix_key));
     st.put(ST_WORD, u2f(job.word));
     st.put(ST_CHUNK, u2f(job.k));                                   // local chunk index of this lane
-    u32 s = (g0 + job.k) * kChunk;                                  // global sample index
+    u32 s = (g0 + job.k) << csh;                                    // global sample index
     if (s < s_base) s = s_base;
     {
-        u32 e = (g0 + job.k + 1u) * kChunk;
+        u32 e = (g0 + job.k + 1u) << csh;
         if (e > s_stop) e = s_stop;
         st.put(ST_SEND, u2f(e));
     }
@@ -1336,8 +1336,8 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                 csum = v3(0.0f, 0.0f, 0.0f);
                 j += P.k_split;
                 alive = j < n_chunks;
-                s = (g0 + j) * kChunk;
-                u32 e = s + kChunk;
+                s = (g0 + j) << csh;
+                u32 e = s + (1u << csh);
                 if (e > s_stop) e = s_stop;
                 st.put(ST_CHUNK, u2f(j));
                 st.put(ST_SEND, u2f(e));

@@ -383,6 +383,67 @@ def test_per_call_loop_equals_one_batched_call():
     assert np.array_equal(a.img(), b.img()) or np.abs(a.img().astype(int) - b.img().astype(int)).max() <= 1
 
 
+def test_look_ahead_serves_the_per_call_loop_bit_for_bit():
+    """The eager per-call loop (one mrt_execute per sample, src/cli.rs:162-170) is served from look-ahead launches from the
+    third consecutive one-sample call on (csrc/mrt_api.cpp run_lookahead): the accumulator holds exactly the requested
+    samples at EVERY return, bit for bit what the plain one-sample launches leave there; a batched call, a reset or a restored
+    accumulator in the middle drops what was traced ahead and changes nothing."""
+    from micro_raytracer_amd import Sampler, _abi, scenes
+    for desc in (scenes.cornell_box(res=(96, 64), sample=45), scenes.kitchen_sink(res=(64, 40), sample=45)):
+        render, _ = make_holder(desc)
+        plain, ahead = Sampler(seed=5, flags=_abi.FLAG_NO_LOOKAHEAD), Sampler(seed=5)
+        for i in range(45):
+            plain.execute(render)
+            ahead.execute(render)
+            if i in (0, 1, 2, 3, 4, 7, 8, 20, 44):       # direct calls, first look-ahead sets, set boundaries, the 16-sample sets
+                a, ca = plain.accum()
+                b, cb = ahead.accum()
+                assert ca == cb == i + 1 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+        assert ahead.stats()["samples"] == plain.stats()["samples"] and ahead.stats()["kernel_ms"] > 0
+        assert np.array_equal(plain.img(), ahead.img())
+        # a batched call in the middle: what was ahead is dropped, the samples are the same ones
+        for s in (plain, ahead):
+            s.execute(render, n_samples=19)
+            for _ in range(5):
+                s.execute(render)
+        a, ca = plain.accum()
+        b, cb = ahead.accum()
+        assert ca == cb == 69 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        # reset, then a restored accumulator: the loop picks up at the restored count
+        keep, cnt = ahead.accum()
+        for s in (plain, ahead):
+            s.reset()
+            for _ in range(4):
+                s.execute(render)
+            s.set_accum(keep, cnt)
+            for _ in range(6):
+                s.execute(render)
+        a, ca = plain.accum()
+        b, cb = ahead.accum()
+        assert ca == cb == 75 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        plain.close(); ahead.close()
+
+
+def test_look_ahead_on_a_row_shard_and_with_a_bound_accumulator():
+    """Row shards run their own look-ahead; the accumulator may live in caller memory (mrt_bind_accum is what a rank of the
+    multi-GPU path does): it still holds exactly the requested samples at every return."""
+    from micro_raytracer_amd import Sampler, _abi, scenes
+    render, _ = make_holder(scenes.cornell_box2(res=(80, 56), ssaa=1, sample=12))
+    whole = Sampler(seed=6, flags=_abi.FLAG_NO_LOOKAHEAD)
+    for _ in range(12):
+        whole.execute(render)
+    ref, _ = whole.accum()
+    got = np.zeros_like(ref)
+    for r in range(3):
+        s = Sampler(seed=6, shard_index=r, shard_count=3)
+        for _ in range(12):
+            s.execute(render)
+        loc, rows = s.accum_local()
+        got[rows] = loc
+        assert s.stats()["launches"] == 1
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+
+
 def test_deferred_execution_books_calls_and_traces_them_batched():
     """MRT_FLAG_DEFER: the per-call loop of the reference's callers (src/cli.rs:162-170) only books samples; observing the
     accumulator traces them in one batch -- bit-identical to one batched call; with an observation after every call
