@@ -736,7 +736,7 @@ static int exec_group(mrt_ctx *g, uint32_t n_samples)
 // one-sample launch cannot regenerate paths inside a lane (a wavefront lasts as long as its longest path: lane utilisation
 // 0.65 against 0.70, 0.36 ms per 1080p pass against 0.25 inside a batched launch), and the image is a pure function of (scene,
 // seed, sample index) -- so a context that sees one-sample calls arrive back to back traces AHEAD: samples [k, k + n) in one
-// launch on a second stream, every sample into a plane of its own (chunks of one sample, Params.chunk_shift = 0), and each call
+// launch on a second stream, every sample into a plane of its own (Params.to_planes), and each call
 // only folds its sample's plane into the accumulator (reduce_chunks, 0.02 ms) and waits for that.  The accumulator holds
 // exactly the samples the caller has asked for at every return, added one by one in index order -- bit for bit what the plain
 // per-call loop leaves there -- so observing it (mrt_accum, mrt_img, a bound or handed-out pointer) needs no special case.  Two
@@ -765,7 +765,7 @@ static int la_launch(mrt_ctx *c, int i, u32 base, u32 n)
         c->la_floats[i] = plane * n;
     }
     Params P = c->P;
-    P.n_samples = n; P.sample_base = base; P.k_split = 1u; P.chunk_shift = 0u; P.to_planes = 1u;
+    P.n_samples = n; P.sample_base = base; P.k_split = 1u; P.to_planes = 1u;
     P.partial = c->d_la[i]; P.partial_stride = plane;
     P.count_segments = 0u;
     // small scenes: the plain grid (their persistent grid fills every wave slot of the chip and would keep the folds out until

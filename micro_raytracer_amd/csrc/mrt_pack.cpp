@@ -782,7 +782,6 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
     P.lds_words = P.off_leaf;
     B.align4();
     P.blob_words = (u32)B.w.size();
-    P.chunk_shift = kChunkShift; P.to_planes = 0u;
     P.walk_cap = tbvh_tab.empty() ? 0u : (out.tbvh_wide ? kWalkCapDefault : 8u);      // mrt_create adjusts it to the LDS budget (plan_launch)
     out.n_tbvh_nodes = (u32)(tbvh_tab.size() / (out.tbvh_wide ? B4_WORDS : BVH_WORDS));
     out.blob.swap(B.w);

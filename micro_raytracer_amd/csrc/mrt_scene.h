@@ -113,7 +113,7 @@ enum : u32 { KIND_SPHERE = 0, KIND_PLANE = 1, KIND_BOX = 2, KIND_TRIANGLE = 3, K
 enum : u32 { LK_POINT = 0, LK_DIR = 1 };
 
 // samples per chunk of the canonical accumulation order (mrt_trace.h render_pixel)
-constexpr u32 kChunk = 16, kChunkShift = 4;
+constexpr u32 kChunk = 16;
 
 struct Params {
     // frame / sampling
@@ -121,9 +121,8 @@ struct Params {
     u32 local_rows, shard_index, shard_count, shard_rows;
     u32 n_samples, sample_base;
     u32 k_split;             // lanes per pixel (each owns every k_split-th sample chunk of the launch)
-    u32 chunk_shift;         // log2 of the samples per chunk: 4 (kChunk = 16, the canonical accumulation order) or, for the look-ahead
-                             // launches of the per-call path, 0 -- every sample its own chunk, written to a plane of its own
-    u32 to_planes;           // chunk sums go to `partial` even with k_split == 1 (look-ahead launches: the accumulator is not touched)
+    u32 to_planes;           // look-ahead launches of the per-call path (k_split == 1): every sample is a chunk of its own, written to
+                             // plane (sample - sample_base) of `partial`; the accumulator is not touched
     u32 seed_lo, seed_hi;
     u32 bounce;
     float q;                 // 1 - min(loss, 1), src/rt.rs:571

@@ -1164,10 +1164,12 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     const u32 pix_key = mix32(pixel + P.seed_lo) ^ P.seed_hi;      // path_key = mix32(pix_key + sample * kGold)
     const V3 sky_init = v3(P.sky_init[0], P.sky_init[1], P.sky_init[2]);
     const u32 s_base = P.sample_base, s_stop = P.sample_base + P.n_samples;
-    const u32 csh = P.chunk_shift;                                  // chunks of 1 << csh samples (4: kChunk; 0: look-ahead launches)
-    const u32 g0 = s_base >> csh;
-    const u32 n_chunks = ((s_stop - 1u) >> csh) - g0 + 1u;          // n_samples > 0
-    const bool direct = P.k_split == 1u && P.to_planes == 0u;
+    const u32 g0 = s_base / kChunk;
+    const u32 n_chunks = (s_stop - 1u) / kChunk - g0 + 1u;          // n_samples > 0
+    // look-ahead launches of the per-call path (Params.to_planes, one lane per pixel): every sample is a chunk of its own and
+    // goes to a plane of its own -- plane j holds sample s_base + j -- and the accumulator is not touched
+    const bool planes1 = P.to_planes != 0u;
+    const bool direct = P.k_split == 1u && !planes1;
     if (direct) st_put3(st, ST_ACC, v3(P.accum[job.word], P.accum[job.word + 1u], P.accum[job.word + 2u]));
     st_put3(st, ST_FOCUS, pixel_focus(P, (float)x, (float)y));
 
@@ -1175,14 +1177,15 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     st.put(ST_PIXKEY, u2f(pix_key));
     st.put(ST_WORD, u2f(job.word));
     st.put(ST_CHUNK, u2f(job.k));                                   // local chunk index of this lane
-    u32 s = (g0 + job.k) << csh;                                    // global sample index
-    if (s < s_base) s = s_base;
+    u32 s = (g0 + job.k) * kChunk;                                  // global sample index
+    if (s < s_base || planes1) s = s_base;
     {
-        u32 e = (g0 + job.k + 1u) << csh;
+        u32 e = (g0 + job.k + 1u) * kChunk;
         if (e > s_stop) e = s_stop;
+        if (planes1) e = s_base + 1u;
         st.put(ST_SEND, u2f(e));
     }
-    bool alive = job.k < n_chunks;
+    bool alive = planes1 ? job.k == 0u : job.k < n_chunks;
     V3 csum = v3(0.0f, 0.0f, 0.0f);
     u32 pk = 0, b = 0;
     V3 o = v3(0, 0, 0), d = v3(0, 1, 0);
@@ -1334,11 +1337,18 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                     q[0] = csum.x; q[1] = csum.y; q[2] = csum.z;
                 }
                 csum = v3(0.0f, 0.0f, 0.0f);
-                j += P.k_split;
-                alive = j < n_chunks;
-                s = (g0 + j) << csh;
-                u32 e = s + (1u << csh);
-                if (e > s_stop) e = s_stop;
+                u32 e;
+                if (planes1) {                                      // (wave-uniform) the next sample, the next plane
+                    j += 1u;
+                    alive = s < s_stop;
+                    e = s + 1u;
+                } else {
+                    j += P.k_split;
+                    alive = j < n_chunks;
+                    s = (g0 + j) * kChunk;
+                    e = s + kChunk;
+                    if (e > s_stop) e = s_stop;
+                }
                 st.put(ST_CHUNK, u2f(j));
                 st.put(ST_SEND, u2f(e));
             }
