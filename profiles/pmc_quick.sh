@@ -4,16 +4,17 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1; wl=$2; spp=$3; which=${4:-sq}
-pass() { name=$1; shift; rocprofv3 --pmc "$@" -d gpurun_out/${tag}_pmc_$name -o out --output-format csv -- python3 bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --spp $spp > gpurun_out/${tag}_pmc_$name.log 2>&1; }
+pass() { name=$1; shift; timeout -k 10 240 rocprofv3 --pmc "$@" -d gpurun_out/${tag}_pmc_$name -o out --output-format csv -- python3 bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --spp $spp > gpurun_out/${tag}_pmc_$name.log 2>&1; }
 if [ $which = sq ]; then
 pass sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 pass wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
 names="sq wait"
 else
 pass sqm SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
-pass ta TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
-pass tcp TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum
-pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# (at most two counters of one block per pass: five TA counters at once made rocprofv3 abort and hang, round 4)
+pass ta TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum
+pass tcp TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
+pass tcc TCC_HIT_sum TCC_MISS_sum
 names="sqm ta tcp tcc"
 fi
 python3 - <<PY
