@@ -1110,11 +1110,11 @@ MRT_HD bool coin(float p, u32 pk, u32 dim)
     return draw_u32(pk, dim) < (u32)(p * 4294967296.0f);
 }
 
-// Per-lane state that is only touched between segments (path radiance, throughput, the pixel's accumulator and
-// camera focus point).  RegStash keeps it in registers; LdsStash parks it in a per-lane LDS column (slot-major, so
+// Per-lane state that is only touched between segments (path radiance, throughput, the pixel's camera focus point
+// and chunk bookkeeping).  RegStash keeps it in registers; LdsStash parks it in a per-lane LDS column (slot-major, so
 // lane i always hits bank i) to free VGPRs for the traversal loop without the compiler spilling to scratch,
 // whose write-backs would show up as HBM traffic.  volatile: the values must really live in LDS across the loop.
-enum : u32 { ST_ACC = 0, ST_FOCUS = 3, ST_PIXKEY = 6, ST_CHUNK = 7, ST_SEND = 8, ST_WORD = 9, ST_SLOTS = 10, ST_T = 10, ST_L = 13, ST_SLOTS_TL = 16 };
+enum : u32 { ST_FOCUS = 0, ST_PIXKEY = 3, ST_CHUNK = 4, ST_SEND = 5, ST_WORD = 6, ST_SLOTS = 7, ST_T = 7, ST_L = 10, ST_P0Y = 13, ST_P0Z = 14, ST_PK = 15, ST_SLOTS_TL = 16 };
 // The kernels bound to 6 waves per SIMD (80 VGPRs: instance BVH, no mesh code, warm staging) also park the path's throughput
 // and radiance (T, L: touched between segments only) in the stash instead of leaving them to the register allocator's spills.
 // (The 8-wave plane / sphere kernel of the 256-thread shape, 64 VGPRs + 24 B of scratch, gains nothing from it: 7949 vs 7987.)
@@ -1170,7 +1170,6 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     // goes to a plane of its own -- plane j holds sample s_base + j -- and the accumulator is not touched
     const bool planes1 = P.to_planes != 0u;
     const bool direct = P.k_split == 1u && !planes1;
-    if (direct) st_put3(st, ST_ACC, v3(P.accum[job.word], P.accum[job.word + 1u], P.accum[job.word + 2u]));
     st_put3(st, ST_FOCUS, pixel_focus(P, (float)x, (float)y));
 
     // chunk bookkeeping and the pixel's hash key are only needed when a path starts or a chunk ends: stashed too
@@ -1201,6 +1200,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     u32 seg = 0;
     if (alive) {                                 // first sample of this lane: every lane of the wavefront is here
         pk = mix32(pix_key + s * kGold);
+        if constexpr (kTL) st.put(ST_PK, u2f(pk));
         camera_ray(P, S.F + P.off_cam, st_get3(st, ST_FOCUS), pk, o, d);
     }
 
@@ -1228,8 +1228,14 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
         } else {
             MRT_PROBE(PH_SHADE);
             const Obj ob = obj_of(S, h);
-            const V3 p0 = add(o, muls(d, h.t0));                       // Vec3f::from(&hit.0.ray)
-            const V3 nh0 = to_object(ob, p0);
+            // (6-wave kernels: the path's hash key lives in the lane stash across the queries and is read once per shaded hit)
+            if constexpr (kTL) pk = f2u(st.get(ST_PK));
+            const V3 p0_ = add(o, muls(d, h.t0));                      // Vec3f::from(&hit.0.ray)
+            // hit.0's point is needed again by the scatter and by every light: the 6-wave kernels park two of its components in
+            // the lane stash instead of leaving them to the register allocator's spills (scratch traffic past L2)
+            if constexpr (kTL) { st.put(ST_P0Y, p0_.y); st.put(ST_P0Z, p0_.z); }
+            auto p0 = [&]() { if constexpr (kTL) return v3(p0_.x, st.get(ST_P0Y), st.get(ST_P0Z)); else return p0_; };
+            const V3 nh0 = to_object(ob, p0_);
             const Surf sf0 = surf_of<FEAT>(S, h, ob, nh0);
             const float opacity0 = surf_scalar<FEAT>(S, sf0, MAP_OPACITY, MAT_OPACITY);
             const float metal_c = sf0.M[MAT_METAL];                     // hit.obj.mat.metal, not the map (src/rt.rs:564)
@@ -1248,7 +1254,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                 ++pass;
                 if (refr) { MRT_PROBE(PH_REFRACT); }
                 if (ob.kind != KIND_PLANE) { MRT_PROBE(PH_NORMAL_NONPLANE); }
-                hp = refr ? add(o, muls(d, h.t1)) : p0;                 // recorded hit point: hit.1 or hit.0
+                hp = refr ? add(o, muls(d, h.t1)) : p0();               // recorded hit point: hit.1 or hit.0
                 const V3 nhh = refr ? to_object(ob, hp) : nh0;
                 hn = hit_normal<FEAT>(S, ob, nhh, refr ? h.i1 : h.i0);
                 sfh = sf0;
@@ -1301,8 +1307,9 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
                         t = v3(t.x + spec, t.y + spec, t.z + spec);
                         const V3 term = muls(t, Lt[LIGHT_PWR]);
                         if (term.x == 0.0f && term.y == 0.0f && term.z == 0.0f) continue;
-                        const V3 ls = point ? norm(sub(lv, p0)) : lv;             // l.norm() at hit0
-                        const V3 so = add(p0, muls(ls, kE));                      // Ray::cast_default
+                        const V3 ph0 = p0();
+                        const V3 ls = point ? norm(sub(lv, ph0)) : lv;            // l.norm() at hit0
+                        const V3 so = add(ph0, muls(ls, kE));                     // Ray::cast_default
                         Hit hs;
                         MRT_TICK(1);                                   // shading up to the shadow query (lanes that ask one)
                         const bool blocked = trace<true, FEAT>(S, ray_pre<FEAT>(so, ls), hs);
@@ -1331,7 +1338,10 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
             if (s == f2u(st.get(ST_SEND))) {                        // chunk complete: flush its sum
                 u32 j = f2u(st.get(ST_CHUNK));
                 if (direct) {
-                    st_put3(st, ST_ACC, add(st_get3(st, ST_ACC), csum));
+                    // one lane per pixel: the chunk sum goes straight into the accumulator (chunk order = program order; 24 B of
+                    // traffic per pixel per 16 samples instead of three stash slots held for the whole launch)
+                    float *q = P.accum + f2u(st.get(ST_WORD));
+                    q[0] += csum.x; q[1] += csum.y; q[2] += csum.z;
                 } else {
                     float *q = P.partial + ((size_t)j * P.partial_stride + f2u(st.get(ST_WORD)));
                     q[0] = csum.x; q[1] = csum.y; q[2] = csum.z;
@@ -1355,6 +1365,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
             if (alive) {                                            // next sample: RayTracer::cast, src/rt.rs:916-922
                 MRT_PROBE(PH_REGEN);
                 pk = mix32(f2u(st.get(ST_PIXKEY)) + s * kGold);
+                if constexpr (kTL) st.put(ST_PK, u2f(pk));
                 base = lens_pos(P, pk);
                 X = sub(st_get3(st, ST_FOCUS), base);               // new_dir before .norm()
                 setT(v3(1.0f, 1.0f, 1.0f)); setL(v3(0.0f, 0.0f, 0.0f));
@@ -1367,11 +1378,6 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
         if (from_camera && !(P.cam_ident && nzfin3(nd))) nd = m3mul(S.F + P.off_cam + 9, m3mul(S.F + P.off_cam, nd));   // rot_y * (look * new_dir), src/rt.rs:930
         o = add(base, muls(nd, kE));
         d = nd;
-    }
-    if (direct) {
-        const V3 acc = st_get3(st, ST_ACC);
-        float *q = P.accum + f2u(st.get(ST_WORD));
-        q[0] = acc.x; q[1] = acc.y; q[2] = acc.z;
     }
     segments = seg;
     (void)ticks;
