@@ -1114,11 +1114,15 @@ MRT_HD bool coin(float p, u32 pk, u32 dim)
 // and chunk bookkeeping).  RegStash keeps it in registers; LdsStash parks it in a per-lane LDS column (slot-major, so
 // lane i always hits bank i) to free VGPRs for the traversal loop without the compiler spilling to scratch,
 // whose write-backs would show up as HBM traffic.  volatile: the values must really live in LDS across the loop.
-enum : u32 { ST_FOCUS = 0, ST_PIXKEY = 3, ST_CHUNK = 4, ST_SEND = 5, ST_WORD = 6, ST_SLOTS = 7, ST_T = 7, ST_L = 10, ST_P0Y = 13, ST_P0Z = 14, ST_PK = 15, ST_SLOTS_TL = 16 };
+enum : u32 { ST_FOCUS = 0, ST_PIXKEY = 3, ST_CHUNK = 4, ST_SEND = 5, ST_WORD = 6, ST_SLOTS = 7, ST_P0Y = 7, ST_P0Z = 8, ST_PK = 9, ST_SLOTS_HIT = 10, ST_T = 10, ST_L = 13, ST_SLOTS_TL = 16 };
 // The kernels bound to 6 waves per SIMD (80 VGPRs: instance BVH, no mesh code, warm staging) also park the path's throughput
 // and radiance (T, L: touched between segments only) in the stash instead of leaving them to the register allocator's spills.
 // (The 8-wave plane / sphere kernel of the 256-thread shape, 64 VGPRs + 24 B of scratch, gains nothing from it: 7949 vs 7987.)
 constexpr bool tl_in_stash(u32 feat, u32 /*threads*/) { return (feat & F_COLD) && (feat & F_BVH) && !(feat & F_TRI); }
+// Those kernels also park what a shaded hit needs again after its queries: two components of hit.0's point and the path's hash
+// key (HBM traffic of the Minecraft-shaped scene 3.6 -> 1.7 GB per 32-spp launch: they were spilled to scratch).  (The warm
+// mesh kernels, 4 waves per SIMD at 128 VGPRs, gain nothing from the same three slots: 3421-3427 against 3403-3425 Msamples/s.)
+constexpr bool hit_in_stash(u32 feat, u32 threads) { return tl_in_stash(feat, threads); }
 constexpr u32 stash_slots_for(u32 feat, u32 threads) { return tl_in_stash(feat, threads) ? (u32)ST_SLOTS_TL : (u32)ST_SLOTS; }
 struct RegStash {
     static constexpr bool in_lds = false;
@@ -1190,6 +1194,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     V3 o = v3(0, 0, 0), d = v3(0, 1, 0);
     // path throughput T and radiance L: registers, or (tl_in_stash) two stash columns
     constexpr bool kTL = Stash::in_lds && tl_in_stash(FEAT, Stash::threads);
+    constexpr bool kHit = Stash::in_lds && hit_in_stash(FEAT, Stash::threads);
     V3 T_ = v3(1, 1, 1), L_ = v3(0, 0, 0);
     auto getT = [&]() { if constexpr (kTL) return st_get3(st, ST_T); else return T_; };
     auto getL = [&]() { if constexpr (kTL) return st_get3(st, ST_L); else return L_; };
@@ -1200,7 +1205,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
     u32 seg = 0;
     if (alive) {                                 // first sample of this lane: every lane of the wavefront is here
         pk = mix32(pix_key + s * kGold);
-        if constexpr (kTL) st.put(ST_PK, u2f(pk));
+        if constexpr (kHit) st.put(ST_PK, u2f(pk));
         camera_ray(P, S.F + P.off_cam, st_get3(st, ST_FOCUS), pk, o, d);
     }
 
@@ -1229,12 +1234,12 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
             MRT_PROBE(PH_SHADE);
             const Obj ob = obj_of(S, h);
             // (6-wave kernels: the path's hash key lives in the lane stash across the queries and is read once per shaded hit)
-            if constexpr (kTL) pk = f2u(st.get(ST_PK));
+            if constexpr (kHit) pk = f2u(st.get(ST_PK));
             const V3 p0_ = add(o, muls(d, h.t0));                      // Vec3f::from(&hit.0.ray)
             // hit.0's point is needed again by the scatter and by every light: the 6-wave kernels park two of its components in
             // the lane stash instead of leaving them to the register allocator's spills (scratch traffic past L2)
-            if constexpr (kTL) { st.put(ST_P0Y, p0_.y); st.put(ST_P0Z, p0_.z); }
-            auto p0 = [&]() { if constexpr (kTL) return v3(p0_.x, st.get(ST_P0Y), st.get(ST_P0Z)); else return p0_; };
+            if constexpr (kHit) { st.put(ST_P0Y, p0_.y); st.put(ST_P0Z, p0_.z); }
+            auto p0 = [&]() { if constexpr (kHit) return v3(p0_.x, st.get(ST_P0Y), st.get(ST_P0Z)); else return p0_; };
             const V3 nh0 = to_object(ob, p0_);
             const Surf sf0 = surf_of<FEAT>(S, h, ob, nh0);
             const float opacity0 = surf_scalar<FEAT>(S, sf0, MAP_OPACITY, MAT_OPACITY);
@@ -1365,7 +1370,7 @@ MRT_HD void render_pixel(const Scn &S, Stash &st, u32 x, u32 y, const LaneJob &j
             if (alive) {                                            // next sample: RayTracer::cast, src/rt.rs:916-922
                 MRT_PROBE(PH_REGEN);
                 pk = mix32(f2u(st.get(ST_PIXKEY)) + s * kGold);
-                if constexpr (kTL) st.put(ST_PK, u2f(pk));
+                if constexpr (kHit) st.put(ST_PK, u2f(pk));
                 base = lens_pos(P, pk);
                 X = sub(st_get3(st, ST_FOCUS), base);               // new_dir before .norm()
                 setT(v3(1.0f, 1.0f, 1.0f)); setL(v3(0.0f, 0.0f, 0.0f));
