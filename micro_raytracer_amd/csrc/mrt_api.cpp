@@ -275,11 +275,6 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
     const bool no_lds = getenv("MRT_SCENE_IN_L2") != nullptr;
     const char *force = getenv("MRT_BLOCK_THREADS");
     const bool mesh_walk = pk.n_tbvh_nodes != 0u && (pk.features & 3u) == 3u;
-    // Workgroup-cooperative mesh queries (mrt_coop.h): scenes with a mesh walk and no instance BVH, at the warm or deep level in
-    // 1024-thread persistent workgroups.  MRT_COOP=0 keeps the per-lane kernels.
-    constexpr u32 kCoopDeepCap = 1024u;
-    bool coop_ok = mesh_walk && (pk.features & 16u) == 0u && pk.P.n_inst < (1u << kCoopInstBits) && !getenv("MRT_NO_PERSIST");
-    if (const char *fco = getenv("MRT_COOP")) { if (!atoi(fco)) coop_ok = false; }
     u32 deep_cap = kWalkCapDefault;
     if (const char *fw = getenv("MRT_WALK_CAP")) { const int v = atoi(fw); if (v >= 4 && v <= (int)kWalkCapMax) deep_cap = (u32)v; }
     pk.P.walk_cap = mesh_walk ? kLeafQueue : 0u;         // (only kernels with a walk area count it: pt_lds_bytes)
@@ -317,8 +312,7 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
             PackOpts po; po.tbvh_wide = true;
             Packed again; std::string err2;
             bool ok2 = pack_scene(desc, again, err2, po) == MRT_OK && again.tbvh_wide;
-            const size_t fixed = (size_t)ST_SLOTS * 1024u * sizeof(float) + (size_t)deep_cap * 1024u * sizeof(u32) + 1024u
-                                 + (coop_ok ? (size_t)coop_words(1024u, kCoopDeepCap) * sizeof(u32) : 0u);
+            const size_t fixed = (size_t)ST_SLOTS * 1024u * sizeof(float) + (size_t)deep_cap * 1024u * sizeof(u32) + 1024u;
             const size_t front = ok2 ? (size_t)again.P.off_tbvh * 4 : 0;
             ok2 = ok2 && front + fixed < kLdsLimit;
             if (ok2) {
@@ -333,7 +327,6 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
                     pk = again;
                     pk.features = keep;
                     pk.P.walk_cap = deep_cap;
-                    pk.P.coop_cap = coop_ok ? kCoopDeepCap : 0u;
                     pk.P.n_tbvh_hot = (u32)n;
                     pk.P.lds_words_hot = (pk.P.off_tbvh + (u32)n * B4_WORDS + 3u) & ~3u;
                 }
@@ -351,29 +344,12 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
         // around one LDS copy, so that 32 waves per CU fit: +4 % on the headline frame, +7 % with the 8-wave build of the plane /
         // sphere kernel, +4 % on CornellBox2 -- persistent for batched launches, on the plain grid for launches of less than
         // one sample chunk (a one-sample pass over the 1080p frame: persistent 0.56 ms, single-wave workgroups 0.39, this 0.37)
-        if (cold == kDeep) want = 1024u;                     // (the staged prefix was sized for one 1024-thread workgroup per CU)
-        else if (w256 >= 16u) { want = 256u; pl.small_plain_grid = blob_bytes <= kSmallScene && !cold; }
+        if (w256 >= 16u) { want = 256u; pl.small_plain_grid = blob_bytes <= kSmallScene && !cold; }
         else if (w512 >= 16u) want = 512u;
         else if (w1024 >= 16u) want = 1024u;
         else if (w256 >= w512 && w256 >= 8u) want = 256u;
         else if (!cold && fits(1024u, 32u)) { want = 1024u; marker |= 32u; }      // F_NOSTASH: one LDS copy for 16 waves, lane state in registers
         else want = w1024 ? 1024u : (w512 ? 512u : 256u);
-    }
-    if (force && (u32)atoi(force) != 1024u) coop_ok = false;
-    if (in_lds && coop_ok && (cold & 64u) && want == 1024u) {
-        if (cold == kDeep) {
-            marker |= 256u;                                     // F_COOP (the request queue was reserved with the staged nodes)
-        } else {
-            // warm: two leaf-queue entries per lane go to the request queue; as many records as the LDS has room for
-            pk.P.walk_cap = kLeafQueueCoop;
-            const size_t base = lds_of(1024u, cold);
-            const size_t fixed = (size_t)coop_words(1024u, 0u) * sizeof(u32);
-            const size_t room = base + fixed < kLdsLimit ? (kLdsLimit - base - fixed) / (kCoopRecWords * sizeof(u32)) : 0;
-            if (room >= 256u) { pk.P.coop_cap = room > 2048u ? 2048u : (u32)room; marker |= 256u; }
-            else pk.P.walk_cap = kLeafQueue;
-        }
-    } else if (cold == kDeep && pk.P.coop_cap) {
-        pk.P.coop_cap = 0u;                                     // (reserved, not used: a forced shape)
     }
     if (force && in_lds) {
         const u32 f = (u32)atoi(force);

@@ -14,7 +14,6 @@
 #include "mrt_kernels.h"
 #include "mrt_post.h"
 #include "mrt_trace.h"
-#include "mrt_coop.h"
 
 namespace mrt {
 
@@ -170,59 +169,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS, waves_for(FEAT, BLOCK_THREADS))
     }
 }
 
-// The workgroup-cooperative megakernel (mrt_coop.h): same staging, same lane stash and walk areas as pt_megakernel, plus the
-// request queue behind them; persistent 1024-thread workgroups, one per CU.
-template <int BLOCK_THREADS, u32 FEAT>
-__global__ void __launch_bounds__(BLOCK_THREADS, 4) pt_coopkernel(const Params P, const u32 *__restrict__ blob_g)
-{
-    extern __shared__ uint4 lds_blob[];
-    const u32 staged_words = staged_words_for(P, FEAT);
-    const uint4 *g = reinterpret_cast<const uint4 *>(P.blob);
-    if constexpr (FEAT & F_DEEP) {
-        const u32 n4 = staged_words >> 2;
-        for (u32 i = threadIdx.x; i < n4; i += blockDim.x) lds_blob[i] = g[i];
-    } else {
-        const u32 n4 = staged_words >> 2;
-        for (u32 i = threadIdx.x; i < n4; i += blockDim.x) lds_blob[i] = g[i];
-    }
-    const u32 stash_base4 = (staged_words + 3u) >> 2;
-    float *after = reinterpret_cast<float *>(lds_blob + stash_base4);
-    float *stash = after;
-    float *walk = stash + ST_SLOTS * BLOCK_THREADS;
-    u32 *coop = reinterpret_cast<u32 *>(walk + P.walk_cap * BLOCK_THREADS);
-    // [answers: 2 words per thread][records: coop_cap, cut evenly between the groups][per group: counters 2 x CC_WORDS + barrier word]
-    constexpr u32 kGroups = (u32)BLOCK_THREADS / (64u * kCoopGroupWaves) ? (u32)BLOCK_THREADS / (64u * kCoopGroupWaves) : 1u;
-    const u32 group = threadIdx.x / (64u * kCoopGroupWaves) < kGroups ? threadIdx.x / (64u * kCoopGroupWaves) : 0u;
-    const u32 cap_g = P.coop_cap / kGroups;
-    u32 *ctl = coop + 2u * BLOCK_THREADS + P.coop_cap * kCoopRecWords;
-    Coop C;
-    C.best = (lds_u64 *)coop;
-    C.rec = (lds_u32 *)(coop + 2u * BLOCK_THREADS + group * cap_g * kCoopRecWords);
-    C.cnt = (lds_u32 *)(ctl + group * (2u * CC_WORDS + 4u));
-    C.bar = (lds_u32 *)(ctl + group * (2u * CC_WORDS + 4u) + 2u * CC_WORDS);
-    C.capacity = cap_g;
-    C.epoch = 0u;
-    if (threadIdx.x < 16u * (2u * CC_WORDS + 4u)) ((lds_u32 *)ctl)[threadIdx.x] = 0u;
-    __syncthreads();
-
-    Scn S;
-    S.F = reinterpret_cast<const float *>(lds_blob);
-    S.U = S.F;
-    S.G = reinterpret_cast<const float *>(blob_g);
-    S.P = &P;
-    S.wk = (void *)(walk + threadIdx.x);
-    S.wk_stride = BLOCK_THREADS;
-    LdsStash<BLOCK_THREADS> st;
-    st.base = (lds_vfloat *)(stash + threadIdx.x);
-    u32 segments = 0;
-    render_coop<BLOCK_THREADS, FEAT>(S, C, st, segments);
-    if (P.count_segments) {
-        u32 v = segments;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(P.segments, (unsigned long long)v);
-    }
-}
-
 // acc[p] += chunk sums in chunk order (the canonical order of mrt_trace.h), one thread per accumulator word
 __global__ void __launch_bounds__(256) reduce_chunks(float *__restrict__ accum, const float *__restrict__ partial, size_t n_words,
                                                      size_t stride, u32 n_chunks)
@@ -372,7 +318,6 @@ size_t pt_lds_bytes(const Params &P, u32 block_threads, bool scene_in_lds, u32 f
     lds = (lds + 15u) & ~(size_t)15u;
     if (lds_stash_for(scene_in_lds, (int)block_threads, inst)) lds += (size_t)stash_slots_for(inst, block_threads) * block_threads * sizeof(float);
     if (has_walk_area(inst)) lds += (size_t)P.walk_cap * block_threads * sizeof(u32);
-    if (inst & F_COOP) lds += (size_t)coop_words(block_threads, P.coop_cap) * sizeof(u32);
     return lds;
 }
 
@@ -396,7 +341,6 @@ u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
         return pick | F_BVH | nostash | cold;
     }
     if (!scene_in_lds) return big;
-    if (cold && (features & F_COOP) && block_threads == 1024u && (need & F_TRI)) return big | cold | F_COOP;
     if (cold) return big | cold;
     if (block_threads == 64u || block_threads == 256u) return need;
     return big | nostash;
@@ -421,13 +365,6 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     }
     const size_t lds = pt_lds_bytes(P, block_threads, scene_in_lds, features);
     const u32 inst = pt_instantiation(block_threads, scene_in_lds, features);
-    if (inst & F_COOP) {
-        if (!(block_threads == 1024u && P.persist_grid)) return hipErrorInvalidConfiguration;
-        if (inst == (F_ALL | F_COLD | F_COOP)) hipLaunchKernelGGL((pt_coopkernel<1024, F_ALL | F_COLD | F_COOP>), grid, dim3(1024), lds, stream, P, P.blob);
-        else if (inst == (F_ALL | F_COLD | F_DEEP | F_COOP)) hipLaunchKernelGGL((pt_coopkernel<1024, F_ALL | F_COLD | F_DEEP | F_COOP>), grid, dim3(1024), lds, stream, P, P.blob);
-        else return hipErrorInvalidConfiguration;
-        return hipGetLastError();
-    }
     if (!scene_in_lds) {
         if (block_threads != 256u) return hipErrorInvalidConfiguration;
         switch (inst) { MRT_CASE_L2(F_ALL & ~F_TRI) MRT_CASE_L2(F_ALL) MRT_CASE_L2((F_ALL & ~F_TRI) | F_BVH) MRT_CASE_L2(F_ALL | F_BVH) default: break; }
@@ -462,8 +399,6 @@ hipError_t configure_pt(size_t max_lds_bytes)
     MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512)
     MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) MRT_DEEP2(1024)
 #undef MRT_CASE
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_coopkernel<1024, F_ALL | F_COLD | F_COOP>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_coopkernel<1024, F_ALL | F_COLD | F_DEEP | F_COOP>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
     return hipSuccess;
 }
 

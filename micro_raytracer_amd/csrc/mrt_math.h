@@ -46,10 +46,8 @@ MRT_HD float trunc_(float x) { return __builtin_truncf(x); }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MRT_GENERIC_IEEE)
 #define MRT_FAST_IEEE 1
 MRT_HD bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
-MRT_HD bool wave_any(bool ok) { return __builtin_amdgcn_ballot_w64(ok) != 0ull; }
 #else
 MRT_HD bool wave_all(bool ok) { return ok; }
-MRT_HD bool wave_any(bool ok) { return ok; }
 #endif
 constexpr float kWinLo = 0x1p-40f, kWinHi = 0x1p+40f;
 MRT_HD bool in_window(float x) { const float a = fabs_(x); return a >= kWinLo && a <= kWinHi; }       // false for NaN, 0, inf

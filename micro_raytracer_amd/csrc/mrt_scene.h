@@ -112,13 +112,6 @@ constexpr u32 BVH_END = 0xffffffffu;
 enum : u32 { KIND_SPHERE = 0, KIND_PLANE = 1, KIND_BOX = 2, KIND_TRIANGLE = 3, KIND_MESH = 4 };
 enum : u32 { LK_POINT = 0, LK_DIR = 1 };
 
-// Request queue of the workgroup-cooperative kernels (mrt_coop.h): LDS behind the walk areas
-constexpr u32 kCoopRecWords = 7;      // request: ro (3), rd (3), owner thread << 22 | instance; a closest-hit answer (t0, t1, i0, i1) overwrites the ray
-constexpr u32 kCoopInstBits = 22;
-enum : u32 { CC_NREQ = 0, CC_NEXT = 1, CC_LIVE = 2, CC_WORDS = 4 };   // counters of one phase parity
-// words: per-thread answer word pairs | request records (all groups) | per group of wavefronts: two sets of counters + a barrier word (16 groups at most)
-MRT_HD u32 coop_words(u32 threads, u32 capacity) { return 2u * threads + capacity * kCoopRecWords + 16u * (2u * CC_WORDS + 4u); }
-
 // samples per chunk of the canonical accumulation order (mrt_trace.h render_pixel)
 constexpr u32 kChunk = 16;
 
@@ -150,7 +143,6 @@ struct Params {
     u32 off_rend, off_inst, off_instx, off_xf, off_mat, off_light, off_tex, off_lut, off_mesh, off_tri, off_node, off_leaf;
     u32 off_tbvh, off_memb, off_membe, off_parent;
     u32 n_tbvh_hot;           // F_DEEP: triangle-BVH nodes with index < n_tbvh_hot are in LDS (set by mrt_create from the LDS budget)
-    u32 coop_cap;             // request records of the cooperative kernels' queue (mrt_coop.h), set by mrt_create from the LDS budget
     u32 walk_cap;             // entries of the per-lane walk area of the mesh kernels (LDS column: node stack from the bottom, leaf
                               // queue from the top; mrt_trace.h mesh_isect), set by mrt_create from the LDS budget
     u32 blob_words;

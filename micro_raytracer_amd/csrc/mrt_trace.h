@@ -28,8 +28,6 @@ enum : u32 {
     F_NOSTASH = 32u,  // launch-shape marker, not a scene feature: 1024-thread workgroup whose scene leaves no LDS for the lane stash
     F_COLD = 64u,     // launch-shape marker: membership tables and texels are read from global memory, not staged in LDS
                       // (Params.lds_words_warm)
-    F_COOP = 256u,    // launch-shape marker: the workgroup-cooperative loop of mrt_coop.h (1024-thread workgroups; mesh queries go through
-                      // a request queue in LDS and are walked by full wavefronts)
     F_DEEP = 128u     // with F_COLD, meshes beyond the LDS: triangles stay in global memory too (Params.lds_words_hot) and of the
                       // (level-ordered) triangle-BVH table only the first Params.n_tbvh_hot nodes -- the top levels of every
                       // tree -- are staged
@@ -39,8 +37,7 @@ MRT_HD u32 staged_words_for(const Params &P, u32 feat) { return (feat & F_DEEP) 
 // Mesh kernels that leave the cold tables out of LDS spend it on a per-lane WALK AREA (behind the lane stash), Params.walk_cap
 // entries per lane: the leaf queue of the binary walk (kLeafQueue entries), or (F_DEEP) node stack + leaf queue of the 4-wide walk.
 constexpr bool has_walk_area(u32 feat) { return (feat & F_TRI) && (feat & F_BOX) && (feat & F_COLD); }
-constexpr u32 kLeafQueue = 8u, kLeafQueueCoop = 6u;      // (the cooperative kernels give two entries to their request queue)
-constexpr u32 leaf_queue_len(u32 feat) { return (feat & F_COOP) ? kLeafQueueCoop : kLeafQueue; }
+constexpr u32 kLeafQueue = 8u;
 
 // Divergence probe: only the x86 build of tests/emu defines MRT_PROBE(phase); in the kernel it is nothing.
 #ifndef MRT_PROBE
@@ -648,7 +645,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             // per round (below) that is 76 box steps + 12 triangle tests per loop iteration on the 967-triangle bench mesh,
             // with one round per walk 46 + 11 (tests/emu/round_probe.cpp).  Shadow queries keep the two-leaf rounds: their
             // first candidate ends the walk.  The candidate set, and with it the answer, is the same in any order.
-            constexpr u32 kQ = leaf_queue_len(FEAT);
+            constexpr u32 kQ = kLeafQueue;
             WalkMem q(S);
             for (;;) {
                 u32 nq = 0u;
