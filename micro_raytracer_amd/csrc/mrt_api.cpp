@@ -143,6 +143,7 @@ struct mrt_ctx {
     u32 knob_max_chunks = 0;                      // MRT_MAX_CHUNKS: chunks per launch (0: kMaxChunksPerLaunch)
     size_t knob_partial_budget = 0;               // MRT_PARTIAL_LIMIT_BYTES (0: kPartialBudgetBytes)
     bool knob_partial_fail = false;               // MRT_PARTIAL_FAIL_ALLOC: the chunk-plane allocation asks for an impossible size
+    bool debug_fallbacks = false;                 // MRT_DEBUG_FALLBACKS: mrt_get_stats prints the reference-walk fallbacks of the mesh queries
     u32 pending = 0;                              // samples requested by deferred mrt_execute calls and not traced yet
     // Look-ahead of the eager per-call path (the reference's callers run one Sampler::execute per sample, src/cli.rs:162-170):
     // see run_lookahead.  Two sets of per-sample planes [n][padded_rows][nw][3]; set i holds samples [la_base[i], la_base[i] + la_n[i]).
@@ -455,6 +456,7 @@ static mrt_ctx *create_single(const mrt_render_desc *desc, const mrt_opts *opts)
     if (const char *f = getenv("MRT_MAX_CHUNKS")) { const int v = atoi(f); if (v > 0) c->knob_max_chunks = (u32)v; }                   // tests
     if (const char *f = getenv("MRT_PARTIAL_LIMIT_BYTES")) c->knob_partial_budget = (size_t)strtoull(f, nullptr, 10);                  // tests
     c->knob_partial_fail = getenv("MRT_PARTIAL_FAIL_ALLOC") != nullptr;                                                                // tests
+    c->debug_fallbacks = env_on("MRT_DEBUG_FALLBACKS");
     c->la_enabled = !c->defer && (opts->flags & MRT_FLAG_NO_LOOKAHEAD) == 0;
     if (const char *f = getenv("MRT_LOOKAHEAD")) { const int v = atoi(f); if (v <= 1) c->la_enabled = false; else c->la_max = v > 64 ? 64u : (u32)v; }
     {   // both plane sets together stay below 4 GiB (32 samples of a 1080p frame: 2 x 0.8 GB; a 4K frame gets 20 per launch)
@@ -556,6 +558,11 @@ static int resolve_stats(mrt_ctx *c)
         unsigned long long seg = 0;
         HIP_TRY(hipMemcpy(&seg, c->d_segments, sizeof seg, hipMemcpyDeviceToHost));
         c->stats.segments = seg;
+    }
+    if (c->debug_fallbacks) {
+        unsigned long long t[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpy(t, c->d_segments + 5, sizeof t, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[mrt fallbacks] since mrt_create: NaN directions (shortcut) %llu, walk area full %llu, rays the triangle BVH may not cull %llu\n", t[0], t[1], t[2]);
     }
 #ifdef MRT_PHASE_TIMING
     {   // debug build: shader-clock ticks per phase, summed over wavefronts since the context was created

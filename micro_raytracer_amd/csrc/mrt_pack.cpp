@@ -573,7 +573,7 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
             mesh_tab.push_back(oc.root == NO_NODE ? NO_NODE : node0 + oc.root);
             mesh_tab.push_back(leaf0);
             mesh_tab.push_back(mesh_tb);                       // MESH_TBVH (wide table: set when its nodes are laid out)
-            mesh_tab.push_back(0);
+            mesh_tab.push_back((u32)oc.leaf_ids.size());       // MESH_NIDS
             for (int a = 0; a < 3; ++a) mesh_tab.push_back(bits(mesh_c[a]));
             for (int a = 0; a < 3; ++a) mesh_tab.push_back(bits(mesh_h[a]));
             node_tab.insert(node_tab.end(), oc.nodes.begin(), oc.nodes.end());

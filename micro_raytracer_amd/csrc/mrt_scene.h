@@ -61,9 +61,9 @@ enum : u32 { TEX_W = 0, TEX_H = 1, TEX_OFF = 2, TEX_FMT = 3 };
 enum : u32 { TEXFMT_NONE = 0, TEXFMT_F32 = 1, TEXFMT_U8 = 2 };
 
 // MESH: [0] first triangle [1] triangle count [2] root node (0xffffffff: no octree) [3] leaf-id base
-//       [4] root of the mesh's triangle BVH: node index in the TBVH table, binary or 4-wide (0xffffffff: none)  [5] unused
+//       [4] root of the mesh's triangle BVH: node index in the TBVH table, binary or 4-wide (0xffffffff: none)  [5] number of ids in the mesh's octree leaf lists
 //       [6..8] centre, [9..11] half size of the mesh's bounds in mesh coordinates (the culling margin of a ray is derived from them)
-enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4, MESH_BC = 6, MESH_BH = 9 };
+enum : u32 { MESH_TRI0 = 0, MESH_NTRI = 1, MESH_ROOT = 2, MESH_LEAF0 = 3, MESH_TBVH = 4, MESH_NIDS = 5, MESH_BC = 6, MESH_BH = 9 };
 constexpr u32 NO_NODE = 0xffffffffu;
 
 // NODE: [0..2] 0.5*aabb  [3..5] rel_pos  [6] first child node | first leaf id  [7] count | leaf<<31

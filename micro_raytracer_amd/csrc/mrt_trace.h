@@ -61,10 +61,13 @@ constexpr u32 kLeafQueue = 8u;
 #define MRT_TICK_DECL
 #define MRT_TICK_OUT(dst)
 #endif
+#ifndef MRT_PROBE_FALLBACK             // a mesh query that goes to the reference's walk: the ray (tests/emu/probe.cpp prints it)
+#define MRT_PROBE_FALLBACK(ro, rd, dd)
+#endif
 #ifndef MRT_PROBE_ROUND                // one round of a lane's triangle-BVH walk: box steps taken, triangles tested, membership boxes
 #define MRT_PROBE_ROUND(steps, tris, membs)
 #endif
-enum : u32 { CT_TRACE = 0, CT_LIN_TEST, CT_BVH_NODE, CT_BVH_TEST, CT_MESH_CALL, CT_MESH_ROOT_HIT, CT_TBVH_NODE, CT_TBVH_TRI, CT_TBVH_TRI_HIT, CT_MEMB_BOX, CT_TRACE_ANY, CT_WALK_OVERFLOW, CT_WALK_ROUND, CT_COUNT };
+enum : u32 { CT_TRACE = 0, CT_LIN_TEST, CT_BVH_NODE, CT_BVH_TEST, CT_MESH_CALL, CT_MESH_ROOT_HIT, CT_TBVH_NODE, CT_TBVH_TRI, CT_TBVH_TRI_HIT, CT_MEMB_BOX, CT_TRACE_ANY, CT_WALK_OVERFLOW, CT_WALK_ROUND, CT_REF_TRI, CT_REF_BOX, CT_COUNT };
 enum : u32 { PH_ITER = 0, PH_REGEN, PH_SPHERE_MATH, PH_PLANE_HIT, PH_SHADE, PH_NORMAL_NONPLANE, PH_SCATTER1, PH_SCATTER2, PH_REFRACT, PH_EMIT_END, PH_LIGHTS, PH_COUNT };
 
 constexpr float kE = 0.0001f;                 // src/rt.rs:7
@@ -351,21 +354,26 @@ MRT_HD bool cull_ok(V3 o, float dd)     // finite origin within the bounded rang
 {
     return nzfin(dd) && dd > 0.98f && dd < 1.02f && fabs_(o.x) < 1e6f && fabs_(o.y) < 1e6f && fabs_(o.z) < 1e6f;
 }
-// Margin = k x (largest coordinate distance from the origin to the far side of the box) + 1e-5 x the coordinate
-// magnitudes involved (rounding of positions themselves: T + pos, c - o) + 1e-6, DESIGN.md §7.
-//   instance BVH, k = 4e-3: the sphere test's discriminant cancels (b*b - 4ac), so a far, small sphere can answer "hit"
-//     for a ray passing outside it by ~8 eps |oo|^2 / r; 4e-3 covers spheres down to 1/8000 of their distance.
-//   triangle BVH, k = 5e-4: the Moller-Trumbore test has no such cancellation -- a ray it accepts passes within
-//     ~10 eps |tv| = 6e-7 x distance of the triangle at any incidence (near-parallel rays are rejected by |det| < E
-//     before they can amplify) -- so 5e-4 is still ~800 x the bound.
+// Margin = k x (largest coordinate distance from the origin to the far side of the box) + kpos x the coordinate magnitudes
+// involved (rounding of positions themselves: T + pos, c - o) + 1e-6, DESIGN.md section 7.
+//   instance BVH, k = 4e-3, kpos = 1e-5: the sphere test's discriminant cancels (b*b - 4ac), so a far, small sphere can answer
+//     "hit" for a ray passing outside it by ~8 eps |oo|^2 / r; 4e-3 covers spheres down to 1/8000 of their distance.
+//   triangle BVH, k = 5e-5, kpos = 1e-6 (round 4; 5e-4 / 1e-5 before): the Moller-Trumbore test has no such cancellation -- a ray
+//     it accepts passes within ~10 eps |tv| = 6e-7 x distance of the triangle at any incidence (near-parallel rays are
+//     rejected by |det| < E before they can amplify) -- so 5e-5 is ~80 x the bound.  tests/mesh_probe.py (600 k rays: origins up
+//     to 3e5 mesh sizes away, vertex- and edge-aimed, grazing, axis-parallel) finds no difference at these constants, none with
+//     both scaled down by 10, 6 rays with both scaled down by 100, 5762 with no margin at all.  The margin grows with the DISTANCE of the origin, and scenes with a floor plane send rays back from
+//     hundreds of units away (everything a pixel row below the horizon sees): at 5e-4 those rays' margins reached the size of
+//     the triangles and their walks visited most of the tree -- 20 k-triangle bench scene 42 -> 19 ms per launch.
 #ifndef MRT_MARGIN_SCALE            // tests/mesh_probe.py builds with 0 to show that the probe sees an unsafe margin
 #define MRT_MARGIN_SCALE 1.0f
 #endif
-constexpr float kMarginInst = 4e-3f * MRT_MARGIN_SCALE, kMarginTri = 5e-4f * MRT_MARGIN_SCALE;
-MRT_HD float cull_margin(float k, V3 r, V3 h, float big)
+constexpr float kMarginInst = 4e-3f * MRT_MARGIN_SCALE, kMarginTri = 5e-5f * MRT_MARGIN_SCALE;
+constexpr float kMarginPosInst = 1e-5f * MRT_MARGIN_SCALE, kMarginPosTri = 1e-6f * MRT_MARGIN_SCALE;
+MRT_HD float cull_margin(float k, float kpos, V3 r, V3 h, float big)
 {
     const float ext = fmax_(fmax_(fabs_(r.x) + h.x, fabs_(r.y) + h.y), fabs_(r.z) + h.z);
-    return fma_fast(k, ext, fma_fast(1e-5f * MRT_MARGIN_SCALE, big, 1e-6f * MRT_MARGIN_SCALE));
+    return fma_fast(k, ext, fma_fast(kpos, big, 1e-6f * MRT_MARGIN_SCALE));
 }
 MRT_HD bool cull_slab(const CullRay &R, V3 r, V3 h, float mg, float &tn)
 {
@@ -393,6 +401,7 @@ MRT_HD bool mesh_isect_ref(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, f
     auto test = [&](u32 id) {
         if (id == last_id) return;          // Vec::dedup (src/rt.rs:756)
         last_id = id;
+        MRT_COUNT(CT_REF_TRI);
         const float *T = CT + P.off_tri + (tri0 + id) * TRI_WORDS;
         float t;
         if (!tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t)) return;
@@ -415,6 +424,7 @@ MRT_HD bool mesh_isect_ref(const Scn &S, u32 mesh, V3 ro, V3 rd, V3 m, V3 pos, f
         const u32 node = cur[sp]++;
         const float *N = F + P.off_node + node * NODE_WORDS;
         float a0, a1;
+        MRT_COUNT(CT_REF_BOX);
         if (!box_isect(ld3(N, NODE_HALF), ro, m, add(pos, ld3(N, NODE_REL)), a0, a1)) continue;
         const u32 first = ldu(N, NODE_FIRST), cnt = ldu(N, NODE_COUNT);
         if (cnt & 0x80000000u) {
@@ -443,6 +453,18 @@ MRT_HD bool tri_cull_hit(const TriCull &R, float cx, float cy, float cz, float h
     const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
     const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
     return !(tn > tf || tf < 0.0f);
+}
+
+// Diagnostics: mesh queries answered by the reference's own walk instead of a triangle BVH -- slot 6: the 4-wide walk's area
+// was full, slot 7: the ray may not be culled (or the mesh has no tree); slot 5: NaN directions answered by the shortcut.  They are rare and expensive (a wavefront waits for
+// the lane that takes one), so they are counted: MRT_DEBUG_FALLBACKS=1 makes mrt_get_stats print the totals.
+MRT_HD void count_fallback(const Params &P, u32 slot)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_add(P.segments + slot, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    (void)P; (void)slot;
+#endif
 }
 
 // Meshes beyond the LDS (F_DEEP): 4-WIDE triangle BVH (mrt_scene.h) -- a visit decides four subtrees with one round of
@@ -589,6 +611,28 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
     i32 k0 = 0, k1 = 0;
     MRT_COUNT(CT_MESH_CALL);
 
+    // A ray whose direction is NaN in every component (Vec3f::norm of a zero or non-finite vector: a degenerate triangle's
+    // normal, src/rt.rs:457-466, 569) fails every comparison of Box::intersect and Triangle::intersect (src/rt.rs:299-333,
+    // 361-398): every box of the octree "is hit", every listed triangle "is hit" at t = NaN, all keys are equal, and the
+    // reference answers with the FIRST and the LAST triangle of its concatenated leaf lists (min_by keeps the first, max_by the
+    // last of equal elements, src/rt.rs:764-765) -- after testing every triangle of the mesh, some of them many times.  The
+    // same answer from two triangle tests: such rays are one in a million, but the lane that met one kept its wavefront for
+    // tens of milliseconds at the end of a launch (5 k-triangle scene: 59 or 87 ms per launch depending on where they fell).
+    if (rd.x != rd.x && rd.y != rd.y && rd.z != rd.z && root != NO_NODE) {
+        const u32 n_ids = ldu(M, MESH_NIDS), leaf0 = ldu(M, MESH_LEAF0);
+        count_fallback(P, 5);
+        if (n_ids == 0u) return false;
+        if (ANY) return true;
+        const u32 first = ldu(S.G, P.off_leaf + leaf0), last = ldu(S.G, P.off_leaf + leaf0 + n_ids - 1u);
+        const float *T0 = CT + P.off_tri + (tri0 + first) * TRI_WORDS, *T1 = CT + P.off_tri + (tri0 + last) * TRI_WORDS;
+        float ta = 0.0f, tb_ = 0.0f;
+        if (tri_isect(add(ld3(T0, 0), pos), ld3(T0, 3), ld3(T0, 6), ro, rd, ta) && tri_isect(add(ld3(T1, 0), pos), ld3(T1, 3), ld3(T1, 6), ro, rd, tb_)) {
+            t0 = ta; i0 = (i32)first; t1 = tb_; i1 = (i32)last;
+            return true;
+        }
+        // (cannot happen: with a NaN direction no comparison of the triangle test can reject -- the full walk decides)
+    }
+
     if constexpr (FEAT & F_DEEP) {
         // ---- meshes beyond the LDS: the 4-wide table ----
         const V3 ol = sub(ro, pos);
@@ -605,14 +649,16 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                 const V3 c = ld3(M, MESH_BC), hh = ld3(M, MESH_BH);
                 const float big = fmax_(fmax_(fabs_(pos.x), fabs_(pos.y)), fabs_(pos.z)) + fmax_(fmax_(fabs_(c.x) + hh.x, fabs_(c.y) + hh.y), fabs_(c.z) + hh.z)
                                   + fmax_(fmax_(fabs_(ol.x), fabs_(ol.y)), fabs_(ol.z));
-                const float mg = cull_margin(kMarginTri, sub(c, ol), hh, big);
+                const float mg = cull_margin(kMarginTri, kMarginPosTri, sub(c, ol), hh, big);
                 R.oinv = hadam(ol, R.inv);
                 R.qm = muls(R.ainv, mg);
             }
             const int r = mesh_walk4<ANY, FEAT>(S, tb, R, tri0, root, ro, rd, m, pos, t0, i0, t1, i1);
-            if (r == 2) return mesh_isect_ref<ANY, FEAT>(S, mesh, ro, rd, m, pos, t0, i0, t1, i1);
+            if (r == 2) { count_fallback(P, 6); return mesh_isect_ref<ANY, FEAT>(S, mesh, ro, rd, m, pos, t0, i0, t1, i1); }
             return r != 0;
         }
+        count_fallback(P, 7);
+        MRT_PROBE_FALLBACK(ro, rd, dd);
         return mesh_isect_ref<ANY, FEAT>(S, mesh, ro, rd, m, pos, t0, i0, t1, i1);
     }
 
@@ -632,7 +678,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             const V3 c = ld3(M, MESH_BC), hh = ld3(M, MESH_BH);
             const float big = fmax_(fmax_(fabs_(pos.x), fabs_(pos.y)), fabs_(pos.z)) + fmax_(fmax_(fabs_(c.x) + hh.x, fabs_(c.y) + hh.y), fabs_(c.z) + hh.z)
                               + fmax_(fmax_(fabs_(ol.x), fabs_(ol.y)), fabs_(ol.z));
-            const float mg = cull_margin(kMarginTri, sub(c, ol), hh, big);
+            const float mg = cull_margin(kMarginTri, kMarginPosTri, sub(c, ol), hh, big);
             oinv = hadam(ol, R.inv);
             qm = muls(R.ainv, mg);
         }
@@ -776,6 +822,8 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
         return any;
     }
 
+    count_fallback(P, 7);
+    MRT_PROBE_FALLBACK(ro, rd, dd);
     return mesh_isect_ref<ANY, FEAT>(S, mesh, ro, rd, m, pos, t0, i0, t1, i1);
 }
 
@@ -915,7 +963,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
                 const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
                 const V3 c = v3(na.x, na.y, na.z), hh = v3(na.w, nb.x, nb.y);
                 const V3 r = sub(c, R.o);
-                const float mg = cull_margin(kMarginInst, r, hh, obig + obig);
+                const float mg = cull_margin(kMarginInst, kMarginPosInst, r, hh, obig + obig);
                 float tn;
                 bool hit_node = cull_slab(R, r, hh, mg, tn);
                 if (!ANY) hit_node = hit_node && !(tn > far + mg);

@@ -237,6 +237,19 @@ int emu_mesh_probe(const mrt_render_desc *d, uint32_t n, const float *orig, cons
             }
             r[route][0] = h; r[route][1] = h ? f2u(t0) : 0; r[route][2] = h ? (u32)i0 : 0; r[route][3] = h ? f2u(t1) : 0; r[route][4] = h ? (u32)i1 : 0;
         }
+        {   // the reference's own walk, called directly: also checks the shortcut mesh_isect takes for all-NaN directions
+            const float *I = S.F + S.P->off_inst;
+            const F4 ia = ld4(I, 0);
+            const V3 pos = v3(ia.x, ia.y, ia.z);
+            float t0 = 0, t1 = 0; i32 i0 = -1, i1 = -1;
+            const V3 ro = add(pos, sub(ray.o, pos));
+            const bool h = mesh_isect_ref<false, F_ALL>(S, 0, ro, ray.d, ray.m, pos, t0, i0, t1, i1);
+            uint32_t q[5] = {h, h ? f2u(t0) : 0u, h ? (u32)i0 : 0u, h ? f2u(t1) : 0u, h ? (u32)i1 : 0u};
+            // (NaN distances: any NaN matches any NaN, payloads are not part of the contract)
+            const bool nan0 = h && r[0][0] && (u2f(q[1]) != u2f(q[1])) && (u2f(r[0][1]) != u2f(r[0][1]));
+            const bool nan1 = h && r[0][0] && (u2f(q[3]) != u2f(q[3])) && (u2f(r[0][3]) != u2f(r[0][3]));
+            if (q[0] != r[0][0] || (!nan0 && q[1] != r[0][1]) || q[2] != r[0][2] || (!nan1 && q[3] != r[0][3]) || q[4] != r[0][4]) ++bad;
+        }
         if (r[0][0]) ++hits;
         // (triangle ids are positions in the table's leaf order, which both tables share: they come from one binary tree)
         if (memcmp(r[0], r[1], sizeof r[0]) != 0 || memcmp(r[0], r[2], sizeof r[0]) != 0 || anyq[0] != anyq[1] || anyq[0] != anyq[2] || anyq[0] != (bool)r[0][0]) ++bad;

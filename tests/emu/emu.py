@@ -13,7 +13,7 @@ def lib():
     global _LIB
     if _LIB is None:
         subprocess.check_call(["make", "-C", _HERE, "libemu.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        L = C.CDLL(os.path.join(_HERE, "libemu.so"))
+        L = C.CDLL(os.environ.get("MRT_EMU_LIB") or os.path.join(_HERE, "libemu.so"))      # MRT_EMU_LIB: experiment builds (tests/mesh_probe.py with scaled margins)
         L.emu_error.restype = C.c_char_p
         L.emu_pack.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
         L.emu_features.argtypes = [C.c_void_p]

@@ -13,6 +13,8 @@ static thread_local std::vector<uint16_t> *g_rec = nullptr;   // one bitmask per
 #define MRT_PROBE(phase) do { if (g_work && (phase) == 0) { g_work->push_back(0); if (g_work_any) g_work_any->push_back(0); if (g_work_r) { g_work_r->push_back(0); g_work_any_r->push_back(0); } } if (g_rec) { if ((phase) == 0) g_rec->push_back(1); else g_rec->back() |= (uint16_t)(1u << (phase)); } } while (0)
 
 static thread_local uint64_t g_cnt[32];
+static thread_local int g_fallbacks_shown = 0;
+#define MRT_PROBE_FALLBACK(ro, rd, dd) do { if (getenv("MRT_EMU_SHOW_FALLBACKS") && g_fallbacks_shown++ < 30) fprintf(stderr, "fallback ray o = (%g %g %g) d = (%g %g %g) d.d = %.9g   [reference-walk work so far: %llu boxes, %llu triangles]\n", (ro).x, (ro).y, (ro).z, (rd).x, (rd).y, (rd).z, (double)(dd), (unsigned long long)g_cnt[14], (unsigned long long)g_cnt[13]); } while (0)
 static thread_local std::vector<uint32_t> *g_work = nullptr;   // per loop iteration: BVH / TBVH nodes + 3 x exact tests of the lane
 static thread_local std::vector<uint32_t> *g_work_any = nullptr;   // the same for the shadow queries of the iteration
 static thread_local bool g_in_any = false;

@@ -66,8 +66,8 @@ def rays_for(rng, tris, n):
     o = np.where(graz[:, None], a - e * rng.uniform(0.5, 30, (n, 1)) * ext, o)
     d = np.where(graz[:, None], e + tilt, d)
     # far origins aimed at vertices / edges: rounding of the exact test grows with the distance
-    far = (~graz) & (rng.random(n) < 0.15)
-    fo = tgt + (o - tgt) / np.maximum(np.linalg.norm(o - tgt, axis=1, keepdims=True), 1e-30) * (10.0 ** rng.uniform(1, 4, (n, 1))) * ext
+    far = (~graz) & (rng.random(n) < 0.25)
+    fo = tgt + (o - tgt) / np.maximum(np.linalg.norm(o - tgt, axis=1, keepdims=True), 1e-30) * (10.0 ** rng.uniform(1, 5.5, (n, 1))) * ext
     o = np.where(far[:, None], fo, o)
     d = np.where(far[:, None], tgt - fo, d)
     d = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
