@@ -611,26 +611,35 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
     i32 k0 = 0, k1 = 0;
     MRT_COUNT(CT_MESH_CALL);
 
-    // A ray whose direction is NaN in every component (Vec3f::norm of a zero or non-finite vector: a degenerate triangle's
-    // normal, src/rt.rs:457-466, 569) fails every comparison of Box::intersect and Triangle::intersect (src/rt.rs:299-333,
-    // 361-398): every box of the octree "is hit", every listed triangle "is hit" at t = NaN, all keys are equal, and the
-    // reference answers with the FIRST and the LAST triangle of its concatenated leaf lists (min_by keeps the first, max_by the
-    // last of equal elements, src/rt.rs:764-765) -- after testing every triangle of the mesh, some of them many times.  The
-    // same answer from two triangle tests: such rays are one in a million, but the lane that met one kept its wavefront for
-    // tens of milliseconds at the end of a launch (5 k-triangle scene: 59 or 87 ms per launch depending on where they fell).
-    if (rd.x != rd.x && rd.y != rd.y && rd.z != rd.z && root != NO_NODE) {
-        const u32 n_ids = ldu(M, MESH_NIDS), leaf0 = ldu(M, MESH_LEAF0);
-        count_fallback(P, 5);
-        if (n_ids == 0u) return false;
-        if (ANY) return true;
-        const u32 first = ldu(S.G, P.off_leaf + leaf0), last = ldu(S.G, P.off_leaf + leaf0 + n_ids - 1u);
-        const float *T0 = CT + P.off_tri + (tri0 + first) * TRI_WORDS, *T1 = CT + P.off_tri + (tri0 + last) * TRI_WORDS;
-        float ta = 0.0f, tb_ = 0.0f;
-        if (tri_isect(add(ld3(T0, 0), pos), ld3(T0, 3), ld3(T0, 6), ro, rd, ta) && tri_isect(add(ld3(T1, 0), pos), ld3(T1, 3), ld3(T1, 6), ro, rd, tb_)) {
-            t0 = ta; i0 = (i32)first; t1 = tb_; i1 = (i32)last;
+    // Rays that are NaN in every component of their direction (Vec3f::norm of a zero or non-finite vector, src/lin.rs:64-66) or
+    // of their origin (a hit "at t = NaN": Plane::intersect lets 0 / 0 through, src/rt.rs:400-412, and the next ray leaves from
+    // that point) fail every comparison of Box::intersect (src/rt.rs:299-333): every box of the octree "is hit" and every
+    // listed triangle is tested.  Triangle::intersect (src/rt.rs:361-398) can then only reject by |det| < E -- u, v and t are
+    // NaN and pass -- and answers t = NaN, so all keys are equal and the reference returns the FIRST and the LAST accepted
+    // triangle of its concatenated leaf lists (min_by keeps the first, max_by the last of equal elements, src/rt.rs:764-765) --
+    // after testing every triangle of the mesh, some of them several times.  The same answer from the two ends of the list:
+    // such rays are one in ten million, but a path keeps them to its last bounce, and the lane that met one held its wavefront
+    // for ~80 ms at the end of a launch of the 20 k-triangle scene (19 ms otherwise).
+    {
+        const bool d_nan = rd.x != rd.x && rd.y != rd.y && rd.z != rd.z, o_nan = ro.x != ro.x && ro.y != ro.y && ro.z != ro.z;
+        const bool d_num = rd.x == rd.x && rd.y == rd.y && rd.z == rd.z;
+        if (root != NO_NODE && (d_nan || (o_nan && d_num))) {
+            const u32 n_ids = ldu(M, MESH_NIDS), leaf0 = ldu(M, MESH_LEAF0);
+            count_fallback(P, 5);
+            auto accept = [&](u32 at, float &t) {
+                const float *T = CT + P.off_tri + (tri0 + ldu(S.G, P.off_leaf + leaf0 + at)) * TRI_WORDS;
+                return tri_isect(add(ld3(T, 0), pos), ld3(T, 3), ld3(T, 6), ro, rd, t);
+            };
+            u32 a = 0u, b = n_ids;
+            float ta = 0.0f, tb_ = 0.0f;
+            bool found = false;
+            for (; a < n_ids; ++a) if (accept(a, ta)) { found = true; break; }
+            if (!found) return false;
+            if (ANY) return true;
+            while (b-- > a) if (accept(b, tb_)) break;                   // (stops at `a` at the latest)
+            t0 = ta; i0 = (i32)ldu(S.G, P.off_leaf + leaf0 + a); t1 = tb_; i1 = (i32)ldu(S.G, P.off_leaf + leaf0 + b);
             return true;
         }
-        // (cannot happen: with a NaN direction no comparison of the triangle test can reject -- the full walk decides)
     }
 
     if constexpr (FEAT & F_DEEP) {

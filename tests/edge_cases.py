@@ -97,4 +97,16 @@ def cases():
         {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.5], "mat": {"rough": 1}}]
     d["scene"]["light"] = [{"type": "point", "pos": [1.0, -1.5, 1.5], "pwr": 0.6}]
     out["meshes_tbvh_unbounded_empty_coincident"] = d
+
+    # ---- NaN rays against a mesh: the pinhole camera sits IN the edge-on plane, so every ray of the centre row lies in it: Plane::intersect
+    # answers 0 / 0 = NaN, which passes `t <= 0` (src/rt.rs:409): a hit at NaN; the next rays (shadow, bounce) leave from a NaN point and fail
+    # every comparison of the mesh's octree walk -- the kernel answers those from the two ends of the leaf lists (mrt_trace.h mesh_isect)
+    d = _base(res=(32, 20), sample=3, bounce=5, aprt=0.0)
+    d["frame"]["cam"]["pos"] = [0, -1.5, 0.0]
+    d["scene"]["renderer"] = [
+        {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, 0.0], "mat": {"rough": 1}},
+        {"type": "mesh", "mesh": ico, "mat": {"rough": 0.4, "albedo": "#ffb060"}, "inst": [[[0.3, 0.8, 0.1], [0, 0, -1, 0]], [[-0.5, 1.1, 0.2], [0.5, 0.3, -1, 0.2]]]},
+        {"type": "plane", "n": [0, 0, 1], "pos": [0, 0, -0.5], "mat": {"albedo": "#4080ff"}}]
+    d["scene"]["light"] = [{"type": "point", "pos": [1.0, -1.5, 1.5], "pwr": 0.6}]
+    out["meshes_tbvh_nan_origins"] = d
     return out
