@@ -687,6 +687,14 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
         }
     }
     P.n_lin = (u32)lin_list.size(); P.n_bvh_nodes = (u32)(bvh_nodes.size() / BVH_WORDS);
+    {
+        // the culling margin of the instance BVH (mrt_trace.h): the sphere test's discriminant cancels, so a far, small sphere
+        // needs 4e-3 of the origin distance; boxes, triangles and mesh root boxes are tested without such a cancellation
+        bool sphere = false;
+        for (u32 i : bvh_inst) sphere = sphere || (inst_tab[(size_t)i * INST_WORDS + INST_TAG] & TAG_KIND_MASK) == KIND_SPHERE;
+        P.inst_k = sphere ? 4e-3f : 1e-4f;
+        P.inst_kpos = sphere ? 1e-5f : 2e-6f;
+    }
     out.n_lin = P.n_lin; out.n_bvh_nodes = P.n_bvh_nodes;
     P.off_cam = B.align4(); for (int k = 0; k < 9; ++k) B.f(P.cam_L[k]); for (int k = 0; k < 9; ++k) B.f(P.cam_R[k]);      // read by the kernel from here (cold path)
     P.off_lin = B.align4(); B.w.insert(B.w.end(), lin_list.begin(), lin_list.end());

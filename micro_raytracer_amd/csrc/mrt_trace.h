@@ -356,8 +356,12 @@ MRT_HD bool cull_ok(V3 o, float dd)     // finite origin within the bounded rang
 }
 // Margin = k x (largest coordinate distance from the origin to the far side of the box) + kpos x the coordinate magnitudes
 // involved (rounding of positions themselves: T + pos, c - o) + 1e-6, DESIGN.md section 7.
-//   instance BVH, k = 4e-3, kpos = 1e-5: the sphere test's discriminant cancels (b*b - 4ac), so a far, small sphere can answer
-//     "hit" for a ray passing outside it by ~8 eps |oo|^2 / r; 4e-3 covers spheres down to 1/8000 of their distance.
+//   instance BVH (Params.inst_k / inst_kpos, set by pack_scene): k = 4e-3, kpos = 1e-5 when a sphere is among the bounded instances
+//     -- the sphere test's discriminant cancels (b*b - 4ac), so a far, small sphere can answer "hit" for a ray passing outside it
+//     by ~8 eps |oo|^2 / r; 4e-3 covers spheres down to 1/8000 of their distance -- and k = 1e-4, kpos = 2e-6 otherwise (round 4):
+//     Box::intersect, Triangle::intersect and the mesh arm's root-box test carry a few eps x distance of rounding, ~500 x less than
+//     that margin (Minecraft-shaped scene +3 %: its floor plane sends rays back from hundreds of units away, whose 4e-3 margins
+//     were larger than the boxes).
 //   triangle BVH, k = 5e-5, kpos = 1e-6 (round 4; 5e-4 / 1e-5 before): the Moller-Trumbore test has no such cancellation -- a ray
 //     it accepts passes within ~10 eps |tv| = 6e-7 x distance of the triangle at any incidence (near-parallel rays are
 //     rejected by |det| < E before they can amplify) -- so 5e-5 is ~80 x the bound.  tests/mesh_probe.py (600 k rays: origins up
@@ -368,8 +372,7 @@ MRT_HD bool cull_ok(V3 o, float dd)     // finite origin within the bounded rang
 #ifndef MRT_MARGIN_SCALE            // tests/mesh_probe.py builds with 0 to show that the probe sees an unsafe margin
 #define MRT_MARGIN_SCALE 1.0f
 #endif
-constexpr float kMarginInst = 4e-3f * MRT_MARGIN_SCALE, kMarginTri = 5e-5f * MRT_MARGIN_SCALE;
-constexpr float kMarginPosInst = 1e-5f * MRT_MARGIN_SCALE, kMarginPosTri = 1e-6f * MRT_MARGIN_SCALE;
+constexpr float kMarginTri = 5e-5f * MRT_MARGIN_SCALE, kMarginPosTri = 1e-6f * MRT_MARGIN_SCALE;
 MRT_HD float cull_margin(float k, float kpos, V3 r, V3 h, float big)
 {
     const float ext = fmax_(fmax_(fabs_(r.x) + h.x, fabs_(r.y) + h.y), fabs_(r.z) + h.z);
@@ -972,7 +975,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
                 const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
                 const V3 c = v3(na.x, na.y, na.z), hh = v3(na.w, nb.x, nb.y);
                 const V3 r = sub(c, R.o);
-                const float mg = cull_margin(kMarginInst, kMarginPosInst, r, hh, obig + obig);
+                const float mg = cull_margin(P.inst_k * MRT_MARGIN_SCALE, P.inst_kpos * MRT_MARGIN_SCALE, r, hh, obig + obig);
                 float tn;
                 bool hit_node = cull_slab(R, r, hh, mg, tn);
                 if (!ANY) hit_node = hit_node && !(tn > far + mg);
