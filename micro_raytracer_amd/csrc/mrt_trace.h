@@ -37,7 +37,10 @@ MRT_HD u32 staged_words_for(const Params &P, u32 feat) { return (feat & F_DEEP) 
 // Mesh kernels that leave the cold tables out of LDS spend it on a per-lane WALK AREA (behind the lane stash), Params.walk_cap
 // entries per lane: the leaf queue of the binary walk (kLeafQueue entries), or (F_DEEP) node stack + leaf queue of the 4-wide walk.
 constexpr bool has_walk_area(u32 feat) { return (feat & F_TRI) && (feat & F_BOX) && (feat & F_COLD); }
-constexpr u32 kLeafQueue = 8u;
+#ifndef MRT_LEAF_QUEUE              // build-time experiment knob (make EXTRA=-D...)
+#define MRT_LEAF_QUEUE 8u
+#endif
+constexpr u32 kLeafQueue = MRT_LEAF_QUEUE;
 
 // Divergence probe: only the x86 build of tests/emu defines MRT_PROBE(phase); in the kernel it is nothing.
 #ifndef MRT_PROBE
