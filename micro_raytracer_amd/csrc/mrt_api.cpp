@@ -268,8 +268,8 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
     //   wavefront, its own 5.5 KB of LDS -- remain as a forced shape for the tests);
     //   512 threads (4x2 tiles), no stash; 1024 threads (4x4 tiles) + 40 KB stash: one LDS copy serves 16 waves.
     // Mesh kernels of the warm and deep levels own a per-lane walk area (Params.walk_cap entries, mrt_trace.h): the leaf queue
-    // of the binary walk (8 entries, warm), or node stack + leaf queue of the 4-wide walk (16 entries, deep: the scene is
-    // packed again with 4-wide triangle BVHs).
+    // of the binary walk (8 to 16 entries, warm: what the LDS has left), or node stack + leaf queue of the 4-wide walk (16
+    // entries, deep: the scene is packed again with 4-wide triangle BVHs).
     // Environment (experiments, tests; read here, once): MRT_COLD=0/1 forbids / forces the warm level, MRT_DEEP_NODES=n forces
     // the deep level with n staged nodes, MRT_SCENE_IN_L2 forces none, MRT_BLOCK_THREADS forces a workgroup size, MRT_WALK_CAP
     // the entries of the deep level's walk area.
@@ -357,6 +357,15 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
         if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; pl.small_plain_grid = false; } }
     }
     pk.features = (pk.features & 31u) | marker;
+    // the leaf queue of the warm mesh kernels takes what the LDS has left while the workgroups per CU stay the same (967-triangle
+    // bench scene: 13 entries, +2 % over 8: fewer walks need a second round)
+    if (in_lds && marker == kWarm && mesh_walk && has_walk_area(pk.features)) {
+        const size_t w0 = waves(want, marker);
+        while (pk.P.walk_cap < kWalkCapMax) {
+            ++pk.P.walk_cap;
+            if (waves(want, marker) != w0) { --pk.P.walk_cap; break; }
+        }
+    }
     pl.in_lds = in_lds;
     pl.block_threads = want;
     pl.staged_bytes = blob_bytes;

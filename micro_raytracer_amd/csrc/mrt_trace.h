@@ -37,6 +37,10 @@ MRT_HD u32 staged_words_for(const Params &P, u32 feat) { return (feat & F_DEEP) 
 // Mesh kernels that leave the cold tables out of LDS spend it on a per-lane WALK AREA (behind the lane stash), Params.walk_cap
 // entries per lane: the leaf queue of the binary walk (kLeafQueue entries), or (F_DEEP) node stack + leaf queue of the 4-wide walk.
 constexpr bool has_walk_area(u32 feat) { return (feat & F_TRI) && (feat & F_BOX) && (feat & F_COLD); }
+#ifndef MRT_SHADOW_QUEUE            // 1: shadow walks of kernels with a walk area postpone every leaf too (experiment: the x86 round
+                                    // model says -12 % box steps per wavefront, the GPU 3669 against 3721 Msamples/s: off)
+#define MRT_SHADOW_QUEUE 0
+#endif
 #ifndef MRT_LEAF_QUEUE              // build-time experiment knob (make EXTRA=-D...)
 #define MRT_LEAF_QUEUE 8u
 #endif
@@ -699,14 +703,14 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
         }
         u32 s0 = 0, s1 = 0;
         u32 node = tb;
-        if constexpr (!ANY && has_walk_area(FEAT)) {
+        if constexpr ((!ANY || MRT_SHADOW_QUEUE) && has_walk_area(FEAT)) {
             // Closest-hit walk with EVERY leaf postponed: the box walk runs on until the tree is exhausted (or the lane's queue
-            // of kQ leaves is full), then the exact tests of all queued leaves run together, one triangle per lane per trip.
+            // of kQ = Params.walk_cap leaves is full), then the exact tests of all queued leaves run together, one triangle per lane per trip.
             // A wavefront pays, per round, the longest box walk and the longest triangle list of its lanes: with two leaves
             // per round (below) that is 76 box steps + 12 triangle tests per loop iteration on the 967-triangle bench mesh,
             // with one round per walk 46 + 11 (tests/emu/round_probe.cpp).  Shadow queries keep the two-leaf rounds: their
             // first candidate ends the walk.  The candidate set, and with it the answer, is the same in any order.
-            constexpr u32 kQ = kLeafQueue;
+            const u32 kQ = P.walk_cap;                             // kLeafQueue entries at least (plan_launch)
             WalkMem q(S);
             for (;;) {
                 u32 nq = 0u;
@@ -753,6 +757,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                             n = ldu(F, P.off_parent + n);
                         }
                         if (!reached) continue;
+                        if (ANY) return true;
                         const u32 slot = w & MEMB_SLOT_MASK;    // entries are in slot order
                         if (!cand) sl = slot;
                         sh = slot;

@@ -15,6 +15,9 @@ static thread_local std::vector<std::vector<Call>> *g_iters = nullptr;     // [i
 #include "../../micro_raytracer_amd/csrc/mrt_pack.h"
 #include "../../micro_raytracer_amd/csrc/mrt_trace.h"
 using namespace mrt;
+#ifndef ROUND_FEAT                  // -DROUND_FEAT="(F_ALL | F_COLD)": the warm mesh kernel (every closest-hit leaf queued)
+#define ROUND_FEAT F_ALL
+#endif
 
 // out: [0] wave iterations, [1] sum over rounds of max steps, [2] sum of max tris, [3] wave rounds, [4] sum of lane steps / 64, [5] sum of lane tris / 64,
 //      [6] mesh_isect call slots executed by the wave, [7] lane-calls / 64
@@ -32,7 +35,7 @@ extern "C" int probe_rounds(const mrt_render_desc *d, uint64_t seed, uint32_t n_
     for (int l = 0; l < 64; ++l) {
         g_iters = &rec[l];
         u32 sg = 0; RegStash st; LaneJob job; job.k = 0; job.word = ((ty * 8 + (l >> 3)) * pk.nw + tx * 8 + (l & 7)) * 3u;
-        render_pixel<F_ALL>(S, st, tx * 8 + (l & 7), ty * 8 + (l >> 3), job, sg);
+        render_pixel<ROUND_FEAT>(S, st, tx * 8 + (l & 7), ty * 8 + (l >> 3), job, sg);
         g_iters = nullptr;
         if (rec[l].size() > mx) mx = rec[l].size();
     }
