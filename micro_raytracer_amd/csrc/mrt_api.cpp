@@ -257,7 +257,7 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
     // ---- what is staged in LDS, and the launch shape -------------------------------------------------------------------
     // LDS per workgroup = staged scene + lane stash (+ the mesh kernels' walk areas): pt_lds_bytes knows.  Staging levels:
     //   all     the whole packed scene (minus the octree leaf lists);
-    //   warm    F_COLD: membership tables and texels stay in global memory (touched at most once per shaded hit);
+    //   warm    F_COLD: texels stay in global memory (touched at most once per shaded hit); mesh kernels get a per-lane walk area;
     //   deep    F_COLD | F_DEEP: meshes beyond the LDS.  The triangle-BVH table is in level order, so as many of its first
     //           nodes -- the top levels of every tree -- as fit next to the small tables are staged; deeper nodes and the
     //           triangles are read from global memory too;
@@ -287,7 +287,7 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
         return l > kLdsLimit ? (size_t)0 : (shape / 64u) * (kLdsLimit / (l ? l : 1));
     };
     constexpr u32 kWarm = 64u, kDeep = 64u | 128u;       // F_COLD, F_COLD | F_DEEP
-    const bool has_warm = pk.P.lds_words_warm < pk.P.lds_words;
+    const bool has_warm = pk.P.lds_words_warm < pk.P.lds_words || mesh_walk;     // (mesh kernels: the warm marker also buys the walk area)
     u32 cold = 0u;
     bool in_lds = !no_lds;
     if (in_lds) {

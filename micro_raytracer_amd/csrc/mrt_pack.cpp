@@ -752,9 +752,9 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
     // ---- tables a kernel may leave in global memory (mrt_scene.h Params.lds_words_hot / lds_words_warm) ----
     P.lds_words_hot = B.align4();
     P.off_tri = B.align4(); for (float v : tri_tab) B.f(v);
-    P.lds_words_warm = B.align4();
     P.off_memb = B.align4(); B.w.insert(B.w.end(), memb_tab.begin(), memb_tab.end());
     P.off_membe = B.align4(); B.w.insert(B.w.end(), membe_tab.begin(), membe_tab.end());
+    P.lds_words_warm = B.align4();
     // textures: RGB8 + LUT when every texel is exactly k/255 (what a decoded image file is, src/parser.rs:665)
     for (u32 t = 0; t < sc.n_textures; ++t) {
         const mrt_texture &tx = sc.textures[t];

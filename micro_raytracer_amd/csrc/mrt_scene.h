@@ -150,10 +150,11 @@ struct Params {
     u32 blob_words;
     u32 lds_words;            // words a workgroup stages in LDS: everything before the octree leaf lists when every mesh has a
                               // triangle BVH (the lists are then only read, from global memory, by rays that cannot be culled)
-    // Shorter staging prefixes of the blob (table order: records, transforms, materials, LUT, node arrays | triangles |
-    // membership tables, texels | leaf lists), for kernels that leave the rarely touched tables in global memory (L2):
-    u32 lds_words_warm;       // F_COLD: everything up to and including the triangles; membership tables (read per triangle HIT) and
-                              // texels (one lookup per shaded hit) stay out -- their LDS goes to the per-lane leaf queue of the mesh walk
+    // Shorter staging prefixes of the blob (table order: records, transforms, materials, LUT, node arrays | triangles,
+    // membership tables | texels | leaf lists), for kernels that leave the rarely touched tables in global memory (L2):
+    u32 lds_words_warm;       // F_COLD: everything up to and including triangles and membership tables; texels (one lookup per shaded
+                              // hit) stay out.  (Until round 4 the membership tables -- two dependent reads per triangle HIT -- stayed out
+                              // too: 3713 -> 3808 Msamples/s on the 967-triangle bench scene with them in LDS, at 9 instead of 13 queue entries.)
     u32 lds_words_hot;        // F_COLD | F_DEEP: every table a traversal step reads (records ... node arrays); triangles stay out too.
                               // mrt_create shrinks it to off_tbvh + n_tbvh_hot nodes when not even the node arrays fit
     u32 tiles_x, tiles_y;    // 8x8-pixel wave tiles per workgroup in x and y

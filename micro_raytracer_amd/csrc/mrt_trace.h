@@ -26,7 +26,7 @@ enum : u32 {
     F_ALL = 15u,
     F_BVH = 16u,      // many instances: a BVH over them replaces most of the linear scan (only built with F_ALL)
     F_NOSTASH = 32u,  // launch-shape marker, not a scene feature: 1024-thread workgroup whose scene leaves no LDS for the lane stash
-    F_COLD = 64u,     // launch-shape marker: membership tables and texels are read from global memory, not staged in LDS
+    F_COLD = 64u,     // launch-shape marker: texels are read from global memory, not staged in LDS (mesh kernels: with a per-lane walk area)
                       // (Params.lds_words_warm)
     F_DEEP = 128u     // with F_COLD, meshes beyond the LDS: triangles stay in global memory too (Params.lds_words_hot) and of the
                       // (level-ordered) triangle-BVH table only the first Params.n_tbvh_hot nodes -- the top levels of every
@@ -611,8 +611,8 @@ template <bool ANY, u32 FEAT>
 MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 pos, float &t0, i32 &i0, float &t1, i32 &i1)
 {
     const float *F = S.F;
-    const float *C = (FEAT & F_COLD) ? S.G : S.F;        // membership tables: cold
-    const float *CT = (FEAT & F_DEEP) ? S.G : S.F;       // triangles: cold only for meshes beyond the LDS
+    const float *C = (FEAT & F_DEEP) ? S.G : S.F;        // membership tables and triangles: cold only for meshes beyond the LDS
+    const float *CT = C;
     const Params &P = *S.P;
     const float *M = F + P.off_mesh + mesh * MESH_WORDS;
     const u32 tri0 = ldu(M, MESH_TRI0), root = ldu(M, MESH_ROOT);

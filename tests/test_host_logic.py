@@ -444,11 +444,12 @@ def test_launch_plan_staging_levels_and_shapes(monkeypatch):
         p = plan(d)
         assert (p["staging"], p["block_threads"], p["kernel_features"], p["small_plain_grid"]) == ("all", 256, feat, 1), p
         assert p["staged_bytes"] == p["scene_bytes"] < 6 * 1024 and 8 * p["lds_bytes"] <= LDS
-    # the 967-triangle mesh scene: warm (membership tables + texels out), one 1024-thread workgroup with stash and walk areas
+    # the 967-triangle mesh scene: warm (texels and octree leaf lists out), one 1024-thread workgroup with stash and walk areas
     p = plan(scenes.mesh_scene())
     assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("warm", 1024, 15 | 64), p
-    assert p["walk_cap"] == 13                                      # the leaf queue of the binary walk: 8 + what the LDS has left
-    assert p["staged_bytes"] < p["scene_bytes"] and p["lds_bytes"] == p["staged_bytes"] + 1024 * 4 * (7 + 13) <= LDS < p["lds_bytes"] + 4096
+    # triangles and membership tables staged; the leaf queue of the binary walk: 8 entries + what the LDS has left
+    assert p["walk_cap"] == 9 and p["scene_bytes"] - p["staged_bytes"] < 13 * 1024        # (only the octree leaf lists stay out)
+    assert p["staged_bytes"] < p["scene_bytes"] and p["lds_bytes"] == p["staged_bytes"] + 1024 * 4 * (7 + 9) <= LDS < p["lds_bytes"] + 4096
     assert p["tbvh_hot_nodes"] == p["tbvh_nodes"] > 1000            # binary nodes
     # the Minecraft-shaped scene: warm, 256-thread workgroups (6-wave kernel: six of them per CU), texels out of LDS
     p = plan(scenes.minecraft_like())
