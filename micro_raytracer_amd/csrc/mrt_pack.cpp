@@ -688,11 +688,18 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
     }
     P.n_lin = (u32)lin_list.size(); P.n_bvh_nodes = (u32)(bvh_nodes.size() / BVH_WORDS);
     {
-        // the culling margin of the instance BVH (mrt_trace.h): the sphere test's discriminant cancels, so a far, small sphere
-        // needs 4e-3 of the origin distance; boxes, triangles and mesh root boxes are tested without such a cancellation
+        // the culling margin of the instance BVH (mrt_trace.h), one per ray from the root box: 1e-4 of the origin distance (boxes,
+        // triangles, mesh root boxes: rounding proportional to the distance) + 4e-6 / r_min of its SQUARE when spheres are bounded
+        // (Sphere::intersect's discriminant b*b - 4ac cancels: a ray passing eps |oo|^2 / r outside a sphere can answer "hit")
+        float r_min = 3.0e38f;
         bool sphere = false;
-        for (u32 i : bvh_inst) sphere = sphere || (inst_tab[(size_t)i * INST_WORDS + INST_TAG] & TAG_KIND_MASK) == KIND_SPHERE;
-        P.inst_k = sphere ? 4e-3f : 1e-4f;
+        for (u32 i : bvh_inst) {
+            if ((inst_tab[(size_t)i * INST_WORDS + INST_TAG] & TAG_KIND_MASK) != KIND_SPHERE) continue;
+            sphere = true;
+            for (int a = 0; a < 3; ++a) r_min = std::min(r_min, 0.5f * (bounds[i].mx[a] - bounds[i].mn[a]));
+        }
+        P.inst_k = 1e-4f;
+        P.inst_ksq = !sphere ? 0.0f : (r_min > 1e-12f ? 4e-6f / r_min : 1e30f);
         P.inst_kpos = sphere ? 1e-5f : 2e-6f;
     }
     out.n_lin = P.n_lin; out.n_bvh_nodes = P.n_bvh_nodes;

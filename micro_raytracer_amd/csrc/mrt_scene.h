@@ -137,6 +137,7 @@ struct Params {
     // scene tables
     u32 n_rend, n_light, n_inst;
     u32 n_lin, n_bvh_nodes;   // instance BVH: linear-list length, node count (0: every instance is scanned linearly)
+    float inst_ksq;           // ... and per unit of SQUARED origin distance (spheres among the bounded instances: 4e-6 / smallest radius)
     float inst_k, inst_kpos;  // instance BVH: culling margin per unit of origin distance / of coordinate magnitude (mrt_trace.h cull_margin):
                               // 4e-3 / 1e-5 when a sphere is among the bounded instances, 1e-4 / 2e-6 otherwise (pack_scene)
     u32 off_lin, off_bvh, off_bvhinst;

@@ -363,12 +363,13 @@ MRT_HD bool cull_ok(V3 o, float dd)     // finite origin within the bounded rang
 }
 // Margin = k x (largest coordinate distance from the origin to the far side of the box) + kpos x the coordinate magnitudes
 // involved (rounding of positions themselves: T + pos, c - o) + 1e-6, DESIGN.md section 7.
-//   instance BVH (Params.inst_k / inst_kpos, set by pack_scene): k = 4e-3, kpos = 1e-5 when a sphere is among the bounded instances
-//     -- the sphere test's discriminant cancels (b*b - 4ac), so a far, small sphere can answer "hit" for a ray passing outside it
-//     by ~8 eps |oo|^2 / r; 4e-3 covers spheres down to 1/8000 of their distance -- and k = 1e-4, kpos = 2e-6 otherwise (round 4):
-//     Box::intersect, Triangle::intersect and the mesh arm's root-box test carry a few eps x distance of rounding, ~500 x less than
-//     that margin (Minecraft-shaped scene +3 %: its floor plane sends rays back from hundreds of units away, whose 4e-3 margins
-//     were larger than the boxes).
+//   instance BVH (Params.inst_k / inst_ksq / inst_kpos, set by pack_scene; ONE margin per ray, from the root box): k = 1e-4 --
+//     Box::intersect, Triangle::intersect and the mesh arm's root-box test carry a few eps x distance of rounding, ~500 x less
+//     -- plus, when a sphere is among the bounded instances, ksq x distance^2 with ksq = 4e-6 / smallest radius: the sphere
+//     test's discriminant cancels (b*b - 4ac; rounding eps' ~ 8 eps of |oo|^2), so a ray passing sqrt(r^2 + 2 eps' D^2) - r
+//     <= min(eps' D^2 / r, sqrt(2 eps') D) outside a far, small sphere can answer "hit": ksq x D^2 is 8 x the first bound, and it
+//     is capped at 4e-3 x D, 4 x the second (tests/edge_cases.py bvh_far_tiny_spheres has such hits in most of its pixels).  (Rounds 1-3: 4e-3 x distance per NODE, which covered spheres down to 1/8000 of their distance and,
+//     on the Minecraft-shaped scene, made the margins of rays returning from far floor hits larger than the boxes.)
 //   triangle BVH, k = 5e-5, kpos = 1e-6 (round 4; 5e-4 / 1e-5 before): the Moller-Trumbore test has no such cancellation -- a ray
 //     it accepts passes within ~10 eps |tv| = 6e-7 x distance of the triangle at any incidence (near-parallel rays are
 //     rejected by |det| < E before they can amplify) -- so 5e-5 is ~80 x the bound.  tests/mesh_probe.py (600 k rays: origins up
@@ -961,14 +962,28 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     // ---- BVH over the bounded instances: threaded depth-first walk, one lane = one walk ----
     if constexpr (bvh) {
         // Culling must never drop an instance whose exact test would answer Some.  A node is skipped only when the ray
-        // misses its box grown by 4e-3 x (largest coordinate distance from the origin to the far side of the box): more
-        // than a thousand times the rounding error of the exact tests at that distance.  Rays that are
-        // not finite or not unit length are not culled at all.
+        // misses its box grown by the ray's margin (below): tens to hundreds of times the rounding error of
+        // the exact tests at the ray's distance from the farthest instance.  Rays that are not finite or not unit length
+        // are not culled at all.
         const bool cull = cull_ok(ray.o, ray.dd);
         const CullRay R = cull_ray(ray.o, ray.d);
-        const float obig = fmax_(fmax_(fabs_(ray.o.x), fabs_(ray.o.y)), fabs_(ray.o.z));
         const float *N0 = F + P.off_bvh;
         u32 node = P.n_bvh_nodes ? 0u : BVH_END;
+        // ONE margin per ray, from the root box (node 0): k x its extent seen from the origin + ksq x that extent squared (spheres)
+        // + kpos x the coordinate magnitudes, so that a step is the triangle BVH's: t = c * inv - o * inv -+ (h * |inv| + mg * |inv|)
+        V3 oinv, qm;
+        float mg;
+        {
+            const F4 ra = ld4(N0, 0), rb = ld4(N0, 4);
+            const V3 r = sub(v3(ra.x, ra.y, ra.z), R.o);
+            const float ext = fmax_(fmax_(fabs_(r.x) + ra.w, fabs_(r.y) + rb.x), fabs_(r.z) + rb.y);
+            const float obig = fmax_(fmax_(fabs_(ray.o.x), fabs_(ray.o.y)), fabs_(ray.o.z));
+            // (spheres: sqrt(r^2 + 2 eps' D^2) - r <= min(eps' D^2 / r, sqrt(2 eps') D) -- the square law up to D / r = 1000, 4e-3 D beyond)
+            const float ksq = fmin_(P.inst_ksq * ext, 4e-3f) * MRT_MARGIN_SCALE;
+            mg = fma_fast(P.inst_k * MRT_MARGIN_SCALE + ksq, ext, fma_fast(P.inst_kpos * MRT_MARGIN_SCALE, obig + obig + ext, 1e-6f * MRT_MARGIN_SCALE));
+            oinv = hadam(R.o, R.inv);
+            qm = muls(R.ainv, mg);
+        }
         // "while-while": every lane first walks boxes until it stands on a leaf (cheap iterations, all lanes busy), then
         // the wavefront runs the expensive exact tests of the leaves together.
         for (;;) {
@@ -976,17 +991,17 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
             bool walking = node != BVH_END;        // branch-free step: the loop's only branch is its exit
             // nothing in a node whose near side lies beyond the current closest hit can win; the bound only changes in
             // the exact tests between two box walks
-            const float far = (!ANY && best.rend >= 0 && best.t0 >= 0.0f) ? best.t0 + 1e-3f * best.t0 : kInf;
+            const float far = (!ANY && best.rend >= 0 && best.t0 >= 0.0f) ? best.t0 + 1e-3f * best.t0 + mg : kInf;
             while (walking) {
                 const F4 na = ld4(N0, node * BVH_WORDS), nb = ld4(N0, node * BVH_WORDS + 4);
                 MRT_COUNT(CT_BVH_NODE);
                 const u32 skip = f2u(nb.z), leaf = f2u(nb.w);
-                const V3 c = v3(na.x, na.y, na.z), hh = v3(na.w, nb.x, nb.y);
-                const V3 r = sub(c, R.o);
-                const float mg = cull_margin(P.inst_k * MRT_MARGIN_SCALE, P.inst_kpos * MRT_MARGIN_SCALE, r, hh, obig + obig);
-                float tn;
-                bool hit_node = cull_slab(R, r, hh, mg, tn);
-                if (!ANY) hit_node = hit_node && !(tn > far + mg);
+                const float px = fma_fast(na.x, R.inv.x, -oinv.x), py = fma_fast(na.y, R.inv.y, -oinv.y), pz = fma_fast(na.z, R.inv.z, -oinv.z);
+                const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);
+                const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
+                const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
+                bool hit_node = !(tn > tf || tf < 0.0f);
+                if (!ANY) hit_node = hit_node && !(tn > far);
                 hit_node = hit_node || !cull;      // rays that must not be culled visit everything
                 const u32 cand = hit_node ? leaf : 0u;             // a leaf to test, or 0
                 const bool have_a = leaf_a != 0u;

@@ -83,6 +83,23 @@ def cases():
                                {"type": "sphere", "r": 0.3, "mat": {"albedo": "#2020ff"}, "inst": dup}]
     out["bvh_mixed_rotated_and_coincident"] = d
 
+    # ---- the sphere test's cancellation against the instance BVH's margin: 96 spheres (64 of them emissive) of radius 0.004 .. 0.02, 30 to 900 units
+    # away, seen through a 1.6 degree lens: Sphere::intersect's discriminant (b*b - 4ac, ~1e6 in f32) answers "hit" for rays that pass
+    # up to ~1e-3 x distance OUTSIDE such a sphere -- most "hits" of this frame are of that kind, and a BVH margin sized for exact
+    # geometry would lose them
+    d = _base(res=(96, 64), sample=2, bounce=2, fov=1.6, aprt=0.0)
+    d["frame"]["cam"]["pos"] = [0, 0, 0]
+    rng = np.random.default_rng(4242)
+    far_inst = []
+    for k in range(96):
+        y = float(np.exp(rng.uniform(np.log(30.0), np.log(900.0))))
+        far_inst.append([[float(rng.uniform(-0.012, 0.012) * y), y, float(rng.uniform(-0.008, 0.008) * y)], [0, 0, -1, 0]])
+    d["scene"]["renderer"] = [{"type": "sphere", "r": 0.004, "mat": {"emit": 1.0, "albedo": "#ffd040"}, "inst": far_inst[:32]},
+                              {"type": "sphere", "r": 0.02, "mat": {"emit": 1.0, "albedo": "#40d0ff"}, "inst": far_inst[32:64]},
+                              {"type": "sphere", "r": 0.01, "mat": {"rough": 0.5, "albedo": "#ff6060"}, "inst": far_inst[64:]}]
+    d["scene"]["light"] = [{"type": "dir", "dir": [0.2, 1, -0.5], "pwr": 0.8}]
+    out["bvh_far_tiny_spheres"] = d
+
     # ---- meshes: triangle-BVH route next to a mesh that cannot be bounded (reference walk), shared between instances ----
     ico = [[[float(c) for c in v] for v in t] for t in scenes.icosphere(1, 0.35, (1.0, 1.2, 0.8))]
     far = [[[float(c) for c in v] for v in t] for t in scenes.icosphere(0, 0.3)]
