@@ -69,6 +69,9 @@ KERNEL(k_class, "v_cmp_class_f32 vcc, %0, %1")
 KERNEL(k_floor, "v_floor_f32 %0, %0")
 KERNEL(k_fract, "v_fract_f32 %0, %0")
 KERNEL(k_cvtu, "v_cvt_u32_f32 %0, %0")
+KERNEL(k_cmp_cnd, "v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %2, vcc")
+KERNEL(k_cmp_cnd4, "v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %2, vcc\n v_cndmask_b32_e32 %0, %2, %0, vcc\n v_cndmask_b32_e32 %0, %0, %1, vcc")
+KERNEL(k_cmp64_cnd, "v_cmp_gt_f32_e64 s[10:11], %0, %1\n v_cndmask_b32_e64 %0, %0, %2, s[10:11]")
 // packed: register pairs
 __global__ void __launch_bounds__(256) k_pk_fma(float *out, int iters, float s)
 {
@@ -129,5 +132,6 @@ int main()
     run("v_add3_u32", k_add3, d); run("v_or3_b32", k_or3, d); run("v_and_or_b32", k_and_or, d); run("v_mul_hi_u32", k_mulhi, d); run("v_rsq_f32", k_rsq, d);
     run("v_frexp_mant", k_frexp, d); run("v_ldexp_f32", k_ldexp, d); run("v_div_scale", k_divscale, d); run("v_div_fmas", k_divfmas, d); run("v_div_fixup", k_divfixup, d);
     run("v_med3_f32", k_med3, d); run("v_min3_f32", k_min3, d); run("v_cmp_class", k_class, d); run("v_floor_f32", k_floor, d); run("v_fract_f32", k_fract, d); run("v_cvt_u32_f32", k_cvtu, d);
+    run("cmp+cnd (2)", k_cmp_cnd, d); run("cmp+3cnd (4)", k_cmp_cnd4, d); run("cmp64+cnd64(2)", k_cmp64_cnd, d);
     return 0;
 }
