@@ -42,6 +42,12 @@ if "SQ_INSTS_VALU_FLOPS_FP32" in pmc and "SQ_INSTS_VALU" in pmc:
     # dynamic instruction mix (wave-instructions per launch); FLOPS_FP32 counts add + mul + 2 x fma + trans
     d["mix"] = {k.replace("SQ_INSTS_VALU_", "").lower(): pmc[k] / pmc["SQ_INSTS_VALU"] for k in pmc if k.startswith("SQ_INSTS_VALU_")}
     d["fp32_flop_wave_instr"] = pmc["SQ_INSTS_VALU_FLOPS_FP32"] * pmc_scale
+if "GRBM_GUI_ACTIVE" in pmc and "SQ_INSTS_VALU" in pmc:
+    # GRBM_GUI_ACTIVE sums the busy cycles of the 8 XCDs (checked on microbench/valu_types.hip, whose instruction counts are exact):
+    # cycles of ONE shader clock = / 8.  VALU wave-instructions per SIMD per shader cycle -- against 0.5 for a stream of full-rate
+    # opcodes with VGPR operands and 0.25 for the half-rate class (compares, selects, min / max, SGPR-operand forms, ...)
+    d["shader_cycles"] = pmc["GRBM_GUI_ACTIVE"] / 8.0
+    d["valu_instr_per_simd_cycle"] = pmc["SQ_INSTS_VALU"] / 1024.0 / d["shader_cycles"]
 if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc:
     d["wait_any_frac"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
     d["wait_inst_any_frac"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
