@@ -37,6 +37,9 @@ MRT_HD u32 staged_words_for(const Params &P, u32 feat) { return (feat & F_DEEP) 
 // Mesh kernels that leave the cold tables out of LDS spend it on a per-lane WALK AREA (behind the lane stash), Params.walk_cap
 // entries per lane: the leaf queue of the binary walk (kLeafQueue entries), or (F_DEEP) node stack + leaf queue of the 4-wide walk.
 constexpr bool has_walk_area(u32 feat) { return (feat & F_TRI) && (feat & F_BOX) && (feat & F_COLD); }
+#ifndef MRT_UNIFORM_TAG              // 0: instance tags stay per-lane values in the linear scans (experiment knob)
+#define MRT_UNIFORM_TAG 1
+#endif
 #ifndef MRT_SHADOW_QUEUE            // 1: shadow walks of kernels with a walk area postpone every leaf too (experiment: the x86 round
                                     // model says -12 % box steps per wavefront, the GPU 3669 against 3721 Msamples/s: off)
 #define MRT_SHADOW_QUEUE 0
@@ -849,13 +852,23 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
 }
 
 // Renderer::intersect for flat instance i (record words ia, ib): the exact test of the reference, src/rt.rs:725-774
-template <bool ANY, u32 FEAT>
+// UNIFORM: every active lane of the wavefront tests the SAME instance (the linear scans).  The kernels with triangle / mesh
+// code then read its tag into a scalar register, so the kind dispatch, the identity test and the transform's address are
+// scalar instructions and scalar branches instead of per-lane compares (4 VALU cycles each, profiles/microbench/
+// valu_types.hip) of a value all lanes share: mesh scenes +1 ... 2 %.  The plane / sphere kernels lose by it (headline 8268 ->
+// 7810 Msamples/s: their scalar unit is as busy as their vector pipes) and keep the per-lane form.
+#if defined(__HIP_DEVICE_COMPILE__)
+MRT_HD u32 wave_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+#else
+MRT_HD u32 wave_uniform(u32 v) { return v; }
+#endif
+template <bool ANY, u32 FEAT, bool UNIFORM = false>
 MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia, const F4 &ib, float &t0, float &t1, i32 &i0, i32 &i1)
 {
     const float *F = S.U;
     const Params &P = *S.P;
     const V3 pos = v3(ia.x, ia.y, ia.z);
-    const u32 tag = f2u(ib.x);
+    const u32 tag = (UNIFORM && (FEAT & F_TRI) && MRT_UNIFORM_TAG) ? wave_uniform(f2u(ib.x)) : f2u(ib.x);
     const u32 kind = tag & TAG_KIND_MASK;
     const bool ident = (tag & TAG_IDENT) != 0;
     const float *X = F + P.off_xf + (tag >> TAG_XF_SHIFT);          // the tag carries the word offset of the transform
@@ -904,12 +917,12 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     // IN_ORDER: candidates arrive in increasing flat index (the linear scan of a scene without an instance BVH), so the
     // first minimum is kept by a strict comparison alone -- an equal key never replaces an earlier candidate, and the
     // initial key 0x7fffffff loses to every real one (a NaN distance maps to 0x80000000, the smallest key).
-    auto consider = [&](u32 i, const F4 &ia, const F4 &ib, auto in_order) -> bool {
+    auto consider = [&](u32 i, const F4 &ia, const F4 &ib, auto in_order, auto uniform) -> bool {
         float t0, t1;
         MRT_COUNT(CT_LIN_TEST);
         MRT_PROBE_INST(i);
         i32 i0, i1;
-        if (!isect_instance<ANY, FEAT>(S, ray, i, ia, ib, t0, t1, i0, i1)) return false;
+        if (!isect_instance<ANY, FEAT, decltype(uniform)::value>(S, ray, i, ia, ib, t0, t1, i0, i1)) return false;
         if (ANY) return true;
         const i32 key = total_key(t0);
         // any order (BVH scenes): the lexicographic minimum of (key, flat index) as ONE unsigned 64-bit compare -- the key with
@@ -926,6 +939,8 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     };
     using InOrder = BoolTag<(FEAT & F_BVH) == 0>;       // BVH scenes keep the general rule for their short linear list too
     using AnyOrder = BoolTag<false>;
+    using Shared = BoolTag<true>;                       // one instance for the whole wavefront (linear scans)
+    using PerLane = BoolTag<false>;                     // BVH leaves: every lane its own
 
     // ---- linear scan: every instance, or (BVH scenes) the ones that cannot be bounded: planes, odd transforms ----
     const bool bvh = (FEAT & F_BVH) != 0;
@@ -938,10 +953,10 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         F4 a0 = ld4(I, 0), a1 = ld4(I, 4), b0 = a0, b1 = a1;
         for (;;) {
             if (j + 1u < n) { b0 = ld4(I, (j + 1u) * INST_WORDS); b1 = ld4(I, (j + 1u) * INST_WORDS + 4); }
-            if (consider(j, a0, a1, InOrder())) return true;
+            if (consider(j, a0, a1, InOrder(), Shared())) return true;
             if (++j >= n) break;
             if (j + 1u < n) { a0 = ld4(I, (j + 1u) * INST_WORDS); a1 = ld4(I, (j + 1u) * INST_WORDS + 4); }
-            if (consider(j, b0, b1, InOrder())) return true;
+            if (consider(j, b0, b1, InOrder(), Shared())) return true;
             if (++j >= n) break;
         }
     } else if (n) {
@@ -955,7 +970,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
                 cur = bvh ? ldu(Lst, j + 1) : j + 1;
                 qa = ld4(I, cur * INST_WORDS); qb = ld4(I, cur * INST_WORDS + 4);
             }
-            if (consider(i, ia, ib, InOrder())) return true;
+            if (consider(i, ia, ib, InOrder(), Shared())) return true;
         }
     }
 
@@ -1014,7 +1029,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
             const u32 cnt_a = leaf_a >> 24, first_a = leaf_a & 0xffffffu, cnt_b = leaf_b >> 24, first_b = leaf_b & 0xffffffu;
             for (u32 k = 0; k < cnt_a + cnt_b; ++k) {
                 const u32 i = ldu(F, P.off_bvhinst + (k < cnt_a ? first_a + k : first_b + (k - cnt_a)));
-                if (consider(i, ld4(I, i * INST_WORDS), ld4(I, i * INST_WORDS + 4), AnyOrder())) return true;
+                if (consider(i, ld4(I, i * INST_WORDS), ld4(I, i * INST_WORDS + 4), AnyOrder(), PerLane())) return true;
             }
         }
     }
