@@ -271,7 +271,7 @@ int mrt_device_count(void);
 /* Test hook, host only (no device needed): what mrt_create would stage in LDS for this scene and the workgroup shape of its
  * launches -- the policy of csrc/mrt_api.cpp as data, so that it can be checked where no GPU exists. */
 typedef struct mrt_plan {
-    uint32_t staging;        /* 0 whole scene | 1 warm: membership tables and texels in global memory | 2 deep: only the first
+    uint32_t staging;        /* 0 whole scene | 1 warm: texels in global memory (mesh kernels: + a per-lane leaf queue) | 2 deep: only the first
                                 tbvh_hot_nodes nodes of the (level-ordered) triangle-BVH table staged, triangles in global
                                 memory | 3 none: everything through L2 */
     uint32_t block_threads;  /* workgroup size of the batched launches */
