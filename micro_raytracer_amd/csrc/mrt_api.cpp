@@ -356,7 +356,7 @@ void plan_launch(const mrt_render_desc *desc, Packed &pk, Plan &pl)
         const u32 f = (u32)atoi(force);
         if ((f == 64u && !cold) || f == 256u || f == 512u || f == 1024u) { if (fits(f, cold)) { want = f; marker = cold; pl.small_plain_grid = false; } }
     }
-    pk.features = (pk.features & 31u) | marker;
+    pk.features = (pk.features & 31u) | marker | (pk.all_ident ? (u32)F_IDENT : 0u);      // (pt_instantiation: which shapes have F_IDENT builds)
     // the leaf queue of the warm mesh kernels takes what the LDS has left while the workgroups per CU stay the same (967-triangle
     // bench scene: 13 entries, +2 % over 8: fewer walks need a second round)
     if (in_lds && marker == kWarm && mesh_walk && has_walk_area(pk.features)) {

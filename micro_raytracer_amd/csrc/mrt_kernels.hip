@@ -38,11 +38,12 @@ constexpr bool lds_stash_for(bool scene_in_lds, int block_threads, u32 feat)
 #ifndef MRT_BVH_WAVES
 #define MRT_BVH_WAVES 6
 #endif
-constexpr int waves_for(u32 feat, int block_threads)
+constexpr int waves_for(u32 feat_, int block_threads)
 {
 #ifdef MRT_WAVES_PER_EU
     return MRT_WAVES_PER_EU;
 #else
+    const u32 feat = plain_feat(feat_);      // (F_IDENT changes nothing here)
     // Planes and spheres only (the Cornell box), 256-thread workgroups: 8 waves per SIMD (64 VGPRs).  With single-wave
     // workgroups every wavefront brings its own 5.5 KB of LDS (scene copy + stash) and the CU tops out at 29 of them, so a
     // bound of 8 only bought spills there (-3 %); four waves around one copy need 13 KB and all 32 fit: 7.42 -> 7.93
@@ -342,6 +343,8 @@ u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
     }
     if (!scene_in_lds) return big;
     if (cold) return big | cold;
+    // scenes whose instances are all untransformed: the F_IDENT builds of the plain 256-thread kernels without triangle / map code
+    if (block_threads == 256u && (features & F_IDENT) && (need & (F_TRI | F_MAPS)) == 0u) return need | F_IDENT;
     if (block_threads == 64u || block_threads == 256u) return need;
     return big | nostash;
 }
@@ -352,6 +355,7 @@ u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
     MRT_CASE(T, 8) MRT_CASE(T, 9) MRT_CASE(T, 10) MRT_CASE(T, 11) MRT_CASE(T, 12) MRT_CASE(T, 13) MRT_CASE(T, 14) MRT_CASE(T, 15)
 #define MRT_BVH4(T, X) MRT_CASE(T, F_BVH | (X)) MRT_CASE(T, F_LIGHTS | F_BVH | (X)) MRT_CASE(T, (F_ALL & ~F_TRI) | F_BVH | (X)) MRT_CASE(T, F_ALL | F_BVH | (X))
 #define MRT_BIG2(T, X) MRT_CASE(T, (F_ALL & ~F_TRI) | (X)) MRT_CASE(T, F_ALL | (X))
+#define MRT_IDENT4(T) MRT_CASE(T, F_IDENT) MRT_CASE(T, F_IDENT | F_BOX) MRT_CASE(T, F_IDENT | F_LIGHTS) MRT_CASE(T, F_IDENT | F_BOX | F_LIGHTS)
 #define MRT_DEEP2(T) MRT_CASE(T, F_ALL | F_COLD | F_DEEP) MRT_CASE(T, F_ALL | F_BVH | F_COLD | F_DEEP)
 
 hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 features, hipStream_t stream)
@@ -371,7 +375,7 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     } else if (block_threads == 64u) {
         switch (inst) { MRT_PLAIN16(64) MRT_BVH4(64, 0u) default: break; }
     } else if (block_threads == 256u) {
-        switch (inst) { MRT_PLAIN16(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256) default: break; }
+        switch (inst) { MRT_PLAIN16(256) MRT_IDENT4(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256) default: break; }
     } else if (block_threads == 512u) {
         switch (inst) { MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512) default: break; }
     } else if (block_threads == 1024u) {
@@ -395,7 +399,7 @@ hipError_t configure_pt(size_t max_lds_bytes)
     hipError_t e;
 #define MRT_CASE(T, F) if ((e = set_lds_attr<T, (F)>(b)) != hipSuccess) return e;
     MRT_PLAIN16(64) MRT_BVH4(64, 0u)
-    MRT_PLAIN16(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256)
+    MRT_PLAIN16(256) MRT_IDENT4(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256)
     MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512)
     MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) MRT_DEEP2(1024)
 #undef MRT_CASE

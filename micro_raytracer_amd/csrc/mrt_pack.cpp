@@ -687,6 +687,8 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
         }
     }
     P.n_lin = (u32)lin_list.size(); P.n_bvh_nodes = (u32)(bvh_nodes.size() / BVH_WORDS);
+    out.all_ident = n_inst_total > 0;
+    for (u32 i = 0; i < n_inst_total; ++i) out.all_ident = out.all_ident && (inst_tab[(size_t)i * INST_WORDS + INST_TAG] & TAG_IDENT) != 0u;
     {
         // the culling margin of the instance BVH (mrt_trace.h), one per ray from the root box: 1e-4 of the origin distance (boxes,
         // triangles, mesh root boxes: rounding proportional to the distance) + 4e-6 / r_min of its SQUARE when spheres are bounded

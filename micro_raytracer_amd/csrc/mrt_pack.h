@@ -16,6 +16,7 @@ struct Packed {
     u32 res_w = 0, res_h = 0;
     float gamma = 0, exp = 0;
     u32 features = 0;            // F_* bits of mrt_trace.h the scene needs
+    bool all_ident = false;      // every instance untransformed (TAG_IDENT): mrt_create adds F_IDENT to the features
     bool tbvh_wide = false;      // the triangle-BVH table is the 4-wide one (PackOpts)
     u32 n_tex_u8 = 0, n_tex_f32 = 0, n_nodes = 0, n_leaf_ids = 0, n_tris = 0, n_xf = 0, n_bvh_nodes = 0, n_lin = 0, n_tbvh_nodes = 0;
 };

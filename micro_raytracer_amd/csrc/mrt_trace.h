@@ -28,10 +28,16 @@ enum : u32 {
     F_NOSTASH = 32u,  // launch-shape marker, not a scene feature: 1024-thread workgroup whose scene leaves no LDS for the lane stash
     F_COLD = 64u,     // launch-shape marker: texels are read from global memory, not staged in LDS (mesh kernels: with a per-lane walk area)
                       // (Params.lds_words_warm)
-    F_DEEP = 128u     // with F_COLD, meshes beyond the LDS: triangles stay in global memory too (Params.lds_words_hot) and of the
+    F_DEEP = 128u,    // with F_COLD, meshes beyond the LDS: triangles stay in global memory too (Params.lds_words_hot) and of the
                       // (level-ordered) triangle-BVH table only the first Params.n_tbvh_hot nodes -- the top levels of every
                       // tree -- are staged
+    F_IDENT = 256u    // EVERY instance of the scene is untransformed (default `dir`: both matrices the identity as values): the
+                      // per-instance identity test of the tag and the transform's address are compiled out of the linear scan --
+                      // ~30 of ~220 cycles per instance on the Cornell box (8236 -> 8700 Msamples/s).  Exists for the plain
+                      // 256-thread kernels of planes / spheres / boxes with and without lights; rays whose shifted origin has a
+                      // zero, infinite or NaN component still take the reference's two mat-vecs (xf_vec)
 };
+constexpr u32 plain_feat(u32 feat) { return feat & ~(u32)F_IDENT; }
 // words of the packed scene a kernel instantiation stages in LDS
 MRT_HD u32 staged_words_for(const Params &P, u32 feat) { return (feat & F_DEEP) ? P.lds_words_hot : ((feat & F_COLD) ? P.lds_words_warm : P.lds_words); }
 // Mesh kernels that leave the cold tables out of LDS spend it on a per-lane WALK AREA (behind the lane stash), Params.walk_cap
@@ -870,7 +876,7 @@ MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia,
     const V3 pos = v3(ia.x, ia.y, ia.z);
     const u32 tag = (UNIFORM && (FEAT & F_TRI) && MRT_UNIFORM_TAG) ? wave_uniform(f2u(ib.x)) : f2u(ib.x);
     const u32 kind = tag & TAG_KIND_MASK;
-    const bool ident = (tag & TAG_IDENT) != 0;
+    const bool ident = (FEAT & F_IDENT) ? true : (tag & TAG_IDENT) != 0;
     const float *X = F + P.off_xf + (tag >> TAG_XF_SHIFT);          // the tag carries the word offset of the transform
     // n_ray.orig = pos + R*(L*(orig - pos)), n_ray.dir = R*(L*dir), src/rt.rs:729-733
     const V3 ro = add(pos, xf_vec(X, ident, sub(ray.o, pos)));

@@ -440,7 +440,8 @@ def test_launch_plan_staging_levels_and_shapes(monkeypatch):
     for k in ("MRT_COLD", "MRT_DEEP_NODES", "MRT_SCENE_IN_L2", "MRT_BLOCK_THREADS"):
         monkeypatch.delenv(k, raising=False)
     # small scenes: the whole scene, four waves around one copy, 8 workgroups per CU; one-sample launches on the plain grid
-    for d, feat in ((scenes.cornell_box(res=(1920, 1080)), 0), (scenes.cornell_box2(res=(1920, 1080)), 1), (scenes.default_scene(), 8)):
+    # (256 = F_IDENT: every instance untransformed; CornellBox2 has a rotated box)
+    for d, feat in ((scenes.cornell_box(res=(1920, 1080)), 0 | 256), (scenes.cornell_box2(res=(1920, 1080)), 1), (scenes.default_scene(), 8 | 256)):
         p = plan(d)
         assert (p["staging"], p["block_threads"], p["kernel_features"], p["small_plain_grid"]) == ("all", 256, feat, 1), p
         assert p["staged_bytes"] == p["scene_bytes"] < 6 * 1024 and 8 * p["lds_bytes"] <= LDS
