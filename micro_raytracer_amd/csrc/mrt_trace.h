@@ -46,6 +46,9 @@ constexpr bool has_walk_area(u32 feat) { return (feat & F_TRI) && (feat & F_BOX)
 #ifndef MRT_UNIFORM_TAG              // 0: instance tags stay per-lane values in the linear scans (experiment knob)
 #define MRT_UNIFORM_TAG 1
 #endif
+#ifndef MRT_T0_FROM_KEY              // 0: the closest hit's t0 is selected per candidate like its other fields (experiment knob)
+#define MRT_T0_FROM_KEY 1
+#endif
 #ifndef MRT_SHADOW_QUEUE            // 1: shadow walks of kernels with a walk area postpone every leaf too (experiment: the x86 round
                                     // model says -12 % box steps per wavefront, the GPU 3669 against 3721 Msamples/s: off)
 #define MRT_SHADOW_QUEUE 0
@@ -939,7 +942,9 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         const bool better = decltype(in_order)::value ? key < best_key : pair < best_pair;
         if (better) {
             best_key = key;
-            best.rend = 0; best.inst = i; best.t0 = t0; best.t1 = t1; best.i0 = i0; best.i1 = i1;
+            best.rend = 0; best.inst = i; best.t1 = t1; best.i0 = i0; best.i1 = i1;
+            // (kernels without an instance BVH recover t0 from its key after the scan: one select less per candidate, 4 cycles)
+            if constexpr ((FEAT & F_BVH) != 0 || !MRT_T0_FROM_KEY) best.t0 = t0;
         }
         return false;
     };
@@ -1040,6 +1045,11 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
         }
     }
     if (best.rend < 0) return false;
+    if constexpr ((FEAT & F_BVH) == 0 && MRT_T0_FROM_KEY) {
+        // total_key is its own inverse (the sign bit stays); a NaN distance comes back as a NaN (payloads are not part of the contract)
+        const i32 k = best_key;
+        best.t0 = u2f((u32)(k ^ (i32)(((u32)(k >> 31)) >> 1)));
+    }
     best.rend = (i32)ldu(S.F, P.off_instx + best.inst * INSTX_WORDS + INSTX_REND);
     return true;
 }
