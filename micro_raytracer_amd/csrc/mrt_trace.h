@@ -49,6 +49,9 @@ constexpr bool has_walk_area(u32 feat) { return (feat & F_TRI) && (feat & F_BOX)
 #ifndef MRT_T0_FROM_KEY              // 0: the closest hit's t0 is selected per candidate like its other fields (experiment knob)
 #define MRT_T0_FROM_KEY 1
 #endif
+#ifndef MRT_NZFIN_PRODUCT            // 0: three class checks per shifted origin instead of one on the product (experiment knob)
+#define MRT_NZFIN_PRODUCT 1
+#endif
 #ifndef MRT_SHADOW_QUEUE            // 1: shadow walks of kernels with a walk area postpone every leaf too (experiment: the x86 round
                                     // model says -12 % box steps per wavefront, the GPU 3669 against 3721 Msamples/s: off)
 #define MRT_SHADOW_QUEUE 0
@@ -124,6 +127,9 @@ MRT_HD bool nzfin(float x)
 #endif
 }
 MRT_HD bool nzfin3(V3 v) { return nzfin(v.x) && nzfin(v.y) && nzfin(v.z); }
+// a SUFFICIENT test with one class check: a finite non-zero product has three finite non-zero factors (a zero factor gives 0 or
+// NaN, an infinite or NaN one inf or NaN); products that under- or overflow (|x y z| outside 1e-45 .. 3e38) answer false
+MRT_HD bool nzfin3_product(V3 v) { return MRT_NZFIN_PRODUCT ? nzfin((v.x * v.y) * v.z) : nzfin3(v); }
 // 24-bit multiply (v_mul_u32_u24: full rate, where v_mul_lo_u32 is not); both factors below 2^24
 MRT_HD u32 mul24(u32 a, u32 b)
 {
@@ -145,7 +151,7 @@ MRT_HD u32 lowest_bit(u32 x) { return (u32)__builtin_ctz(x | 0x80000000u); }
 MRT_HD V3 xf_full(const float *X, V3 v) { return m3mul(X + XF_R, m3mul(X + XF_L, v)); }
 MRT_HD V3 xf_vec(const float *X, bool ident, V3 v)
 {
-    if (ident && nzfin3(v)) return v;
+    if (ident && nzfin3_product(v)) return v;      // (false only sends the vector through the reference's two mat-vecs)
     return xf_full(X, v);
 }
 
