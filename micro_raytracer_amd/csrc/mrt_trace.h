@@ -878,7 +878,7 @@ MRT_HD u32 wave_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int
 MRT_HD u32 wave_uniform(u32 v) { return v; }
 #endif
 template <bool ANY, u32 FEAT, bool UNIFORM = false>
-MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia, const F4 &ib, float &t0, float &t1, i32 &i0, i32 &i1)
+MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia, const F4 &ib, float &t0, float &t1, i32 &i0, i32 &i1, const float *X0 = nullptr)
 {
     const float *F = S.U;
     const Params &P = *S.P;
@@ -886,10 +886,12 @@ MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia,
     const u32 tag = (UNIFORM && (FEAT & F_TRI) && MRT_UNIFORM_TAG) ? wave_uniform(f2u(ib.x)) : f2u(ib.x);
     const u32 kind = tag & TAG_KIND_MASK;
     const bool ident = (FEAT & F_IDENT) ? true : (tag & TAG_IDENT) != 0;
-    const float *X = F + P.off_xf + (tag >> TAG_XF_SHIFT);          // the tag carries the word offset of the transform
+    // the tag carries the word offset of the transform; F_IDENT: all instances share ONE de-duplicated identity entry, X0, and
+    // trace() has already sent the direction through it where that changes bits (ray.d_ok is then true for every lane)
+    const float *X = (FEAT & F_IDENT) ? X0 : F + P.off_xf + (tag >> TAG_XF_SHIFT);
     // n_ray.orig = pos + R*(L*(orig - pos)), n_ray.dir = R*(L*dir), src/rt.rs:729-733
     const V3 ro = add(pos, xf_vec(X, ident, sub(ray.o, pos)));
-    const bool fast_d = ident && ray.d_ok;
+    const bool fast_d = (FEAT & F_IDENT) ? true : (ident && ray.d_ok);
     V3 rd = ray.d, m = ray.m;
     float dd = ray.dd;
     if (!fast_d) {
@@ -920,7 +922,7 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 // BVH variant, visiting candidates in tree order, returns the very same hit.  ANY = true answers only Some / None
 // (the shadow query of src/rt.rs:1036).  The linear loop fetches each record one iteration ahead of its use.
 template <bool ANY, u32 FEAT>
-MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
+MRT_HD bool trace(const Scn &S, const RayPre &ray_, Hit &best)
 {
     const float *F = S.U;
     const Params &P = *S.P;
@@ -932,12 +934,26 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray, Hit &best)
     // IN_ORDER: candidates arrive in increasing flat index (the linear scan of a scene without an instance BVH), so the
     // first minimum is kept by a strict comparison alone -- an equal key never replaces an earlier candidate, and the
     // initial key 0x7fffffff loses to every real one (a NaN distance maps to 0x80000000, the smallest key).
+    // F_IDENT (every instance untransformed): n_ray.dir = R*(L*dir) is the same vector for every instance -- dir itself, or, for a
+    // direction with a zero / infinite / NaN component, what the two identity mat-vecs make of it (src/rt.rs:729-733) -- so it is
+    // formed once per query instead of once per instance
+    const float *X0 = nullptr;
+    RayPre ray_i = ray_;
+    if constexpr (FEAT & F_IDENT) {
+        X0 = F + P.off_xf + (ldu(I, INST_TAG) >> TAG_XF_SHIFT);
+        if (!ray_.d_ok) {
+            ray_i.d = xf_full(X0, ray_.d);
+            if constexpr (FEAT & F_BOX) ray_i.m = recip_patched(ray_i.d);
+            ray_i.dd = dot(ray_i.d, ray_i.d);
+        }
+    }
+    const RayPre &ray = ray_i;
     auto consider = [&](u32 i, const F4 &ia, const F4 &ib, auto in_order, auto uniform) -> bool {
         float t0, t1;
         MRT_COUNT(CT_LIN_TEST);
         MRT_PROBE_INST(i);
         i32 i0, i1;
-        if (!isect_instance<ANY, FEAT, decltype(uniform)::value>(S, ray, i, ia, ib, t0, t1, i0, i1)) return false;
+        if (!isect_instance<ANY, FEAT, decltype(uniform)::value>(S, ray, i, ia, ib, t0, t1, i0, i1, X0)) return false;
         if (ANY) return true;
         const i32 key = total_key(t0);
         // any order (BVH scenes): the lexicographic minimum of (key, flat index) as ONE unsigned 64-bit compare -- the key with
