@@ -884,7 +884,8 @@ MRT_HD bool isect_instance(const Scn &S, const RayPre &ray, u32 i, const F4 &ia,
     const Params &P = *S.P;
     const V3 pos = v3(ia.x, ia.y, ia.z);
     const u32 tag = (UNIFORM && (FEAT & F_TRI) && MRT_UNIFORM_TAG) ? wave_uniform(f2u(ib.x)) : f2u(ib.x);
-    const u32 kind = tag & TAG_KIND_MASK;
+    // (F_IDENT kernels: the kind is all that is left of the tag in the scan; dispatched on a scalar copy of it, +0.7 %)
+    const u32 kind = (UNIFORM && (FEAT & F_IDENT)) ? wave_uniform(tag & TAG_KIND_MASK) : (tag & TAG_KIND_MASK);
     const bool ident = (FEAT & F_IDENT) ? true : (tag & TAG_IDENT) != 0;
     // the tag carries the word offset of the transform; F_IDENT: all instances share ONE de-duplicated identity entry, X0, and
     // trace() has already sent the direction through it where that changes bits (ray.d_ok is then true for every lane)
