@@ -557,6 +557,12 @@ int pack_scene(const mrt_render_desc *d, Packed &out, std::string &err, const Pa
                         q[BVH_SKIP] = fbits(skip >= nn ? BVH_END : mesh_tb + skip);
                     }
                     tbvh_tab.insert(tbvh_tab.end(), tbn.begin(), tbn.end());
+                    // a sentinel behind the tree: the walks go to node + 1 on every hit (a leaf's skip link is its successor in
+                    // depth-first order), which for the LAST leaf of the tree is this node -- a box no ray hits (negative half
+                    // sizes: the near plane lies behind the far plane on every axis), then the end
+                    float sent[BVH_WORDS] = {0.0f, 0.0f, 0.0f, -1e30f, -1e30f, -1e30f, fbits(BVH_END), fbits(0u)};
+                    static_assert(BVH_C == 0 && BVH_H == 3 && BVH_SKIP == 6 && BVH_LEAF == 7 && BVH_WORDS == 8, "sentinel layout");
+                    tbvh_tab.insert(tbvh_tab.end(), sent, sent + BVH_WORDS);
                 }
             }
             for (u32 t = 0; t < o.n_tris; ++t) {

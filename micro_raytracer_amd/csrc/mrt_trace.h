@@ -280,6 +280,7 @@ MRT_HD uint64_t to_index(float v)
 
 #if defined(__HIPCC__) || defined(__HIP__)
 typedef __attribute__((address_space(3))) volatile float lds_vfloat;   // keeps ds_read / ds_write addressing
+typedef __attribute__((address_space(3))) volatile char lds_char;
 #endif
 
 struct Scn {
@@ -301,11 +302,17 @@ struct WalkMem {
     MRT_HD explicit WalkMem(const Scn &S) : b((lds_vfloat *)S.wk), stride(S.wk_stride) {}
     MRT_HD void put(u32 e, u32 v) { b[e * stride] = u2f(v); }
     MRT_HD u32 get(u32 e) const { return f2u(b[e * stride]); }
+    // entry addressed by its byte offset (entry e is at e * pitch()): a running offset costs an add per step where the entry
+    // number costs a shift-add (2 against 4 cycles, profiles/microbench/valu_types.hip)
+    MRT_HD u32 pitch() const { return stride * 4u; }
+    MRT_HD void put_at(u32 off, u32 v) { *(lds_vfloat *)((lds_char *)b + off) = u2f(v); }
 #else
     u32 v[kWalkCapMax];
     MRT_HD explicit WalkMem(const Scn &) {}
     MRT_HD void put(u32 e, u32 x) { v[e] = x; }
     MRT_HD u32 get(u32 e) const { return v[e]; }
+    MRT_HD u32 pitch() const { return 4u; }
+    MRT_HD void put_at(u32 off, u32 x) { v[off >> 2] = x; }
 #endif
 };
 
@@ -732,7 +739,8 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             const u32 kQ = P.walk_cap;                             // kLeafQueue entries at least (plan_launch)
             WalkMem q(S);
             for (;;) {
-                u32 nq = 0u;
+                u32 qo = 0u;                                            // byte offset of the next free queue entry
+                const u32 q_pitch = q.pitch(), q_full = kQ * q_pitch;
                 u32 probe_steps = 0; (void)probe_steps;
                 bool walking = node != BVH_END;
                 while (walking) {
@@ -746,11 +754,14 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                     const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
                     const float tf = fmin_(fmin_(px + qx, py + qy), pz + qz);
                     const bool hit = !(tn > tf || tf < 0.0f);
-                    q.put(nq, leaf);                                   // branch-free: the slot only counts when the leaf was hit
-                    nq += (hit && leaf != 0u) ? 1u : 0u;
-                    node = (hit && leaf == 0u) ? child : skip;
-                    walking = node != BVH_END && nq < kQ;
+                    q.put_at(qo, leaf);                                // branch-free: the slot only counts when the leaf was hit
+                    qo += (hit && leaf != 0u) ? q_pitch : 0u;
+                    // the table is in depth-first order: a leaf's skip link IS the next node (pack_scene puts a never-hit
+                    // sentinel behind the last leaf of a tree), so "hit" alone decides -- one compare less per step
+                    node = hit ? child : skip;
+                    walking = node != BVH_END && qo < q_full;
                 }
+                const u32 nq = qo / q_pitch;
                 if (nq == 0u) { MRT_PROBE_ROUND(probe_steps, 0u, 0u); break; }
                 u32 e = 0u, j = 0u, leaf = q.get(0u), probe_tris = 0; (void)probe_tris;
                 while (e < nq) {
@@ -817,7 +828,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                 const bool have_a = leaf_a != 0u;
                 leaf_b |= have_a ? cand : 0u;
                 leaf_a |= have_a ? 0u : cand;
-                node = (hit && leaf == 0u) ? child : skip;
+                node = hit ? child : skip;                         // (a leaf's skip link is the next node: see above)
                 walking = node != BVH_END && leaf_b == 0u;
             }
             if (leaf_a == 0u) { MRT_PROBE_ROUND(probe_steps, 0u, 0u); break; }

@@ -12,7 +12,11 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        subprocess.check_call(["make", "-C", _HERE, "libemu.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # (one builder at a time: pytest-xdist workers start together, and a second `make` would load a half-written library)
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", _HERE, "libemu.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         L = C.CDLL(os.environ.get("MRT_EMU_LIB") or os.path.join(_HERE, "libemu.so"))      # MRT_EMU_LIB: experiment builds (tests/mesh_probe.py with scaled margins)
         L.emu_error.restype = C.c_char_p
         L.emu_pack.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
