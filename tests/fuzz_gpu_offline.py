@@ -1,5 +1,7 @@
 """Offline GPU fuzz (not collected by pytest): libmrt_hip.so against the oracle on many random and crowd scenes.
-Usage (on the GPU box): python tests/fuzz_gpu_offline.py FIRST LAST [crowd]"""
+Usage (on the GPU box): python tests/fuzz_gpu_offline.py FIRST LAST [crowd|ident]
+`ident`: random scenes with every instance untransformed and an axis-aligned pinhole camera on a lattice point half of the time
+(the F_IDENT kernels; rays and shifted origins with zero components take the reference's mat-vecs)."""
 import os
 import sys
 
@@ -17,12 +19,35 @@ def main():
     from micro_raytracer_amd import Sampler
     first, last = int(sys.argv[1]), int(sys.argv[2])
     crowd = len(sys.argv) > 3 and sys.argv[3] == "crowd"
+    ident = len(sys.argv) > 3 and sys.argv[3] == "ident"
+
+    def ident_scene(seed):
+        d = random_scene(seed)
+        rng = np.random.default_rng(seed + 4242)
+        keep = []
+        for o in d["scene"]["renderer"]:
+            if o["type"] in ("mesh", "triangle"):
+                continue                                      # (plain kernels only: planes, spheres, boxes)
+            o.pop("dir", None)
+            if "inst" in o:
+                o["inst"] = [[[float(round(c * 2) / 2) for c in i[0]], [0, 0, -1, 0]] for i in o["inst"]]
+            elif "pos" in o:
+                o["pos"] = [float(round(c * 2) / 2) for c in o["pos"]]
+            o.get("mat", {}).pop("tex", None)
+            for k in ("rmap", "mmap", "gmap", "omap", "emap"):
+                o.get("mat", {}).pop(k, None)
+            keep.append(o)
+        d["scene"]["renderer"] = keep or [{"type": "sphere", "r": 0.5}]
+        if rng.random() < 0.5:                                # camera on the lattice, looking straight down +y, pinhole
+            cam = d["frame"]["cam"]
+            cam["pos"] = [0.0, -2.0, 0.0]; cam["dir"] = [0, 0, 1, 0]; cam["aprt"] = 0.0
+        return d
     oracle_mod = importlib.import_module("oracle.oracle")
     bad = 0
     worst = 0.0
     shapes = {}
     for seed in range(first, last):
-        render, h = make_holder(crowd_scene(seed) if crowd else random_scene(seed))
+        render, h = make_holder(ident_scene(seed) if ident else (crowd_scene(seed) if crowd else random_scene(seed)))
         spp = render.rt.sample
         o = oracle_mod.Oracle(h, seed=seed)
         o.execute(spp)
@@ -31,7 +56,8 @@ def main():
         s.execute(render, n_samples=spp)
         got, cnt = s.accum()
         st = s.stats()
-        shapes[st["block_threads"]] = shapes.get(st["block_threads"], 0) + 1
+        key = (st["block_threads"], st["kernel_features"]) if ident else st["block_threads"]
+        shapes[key] = shapes.get(key, 0) + 1
         try:
             _check(got, ref, spp)
             fin = np.isfinite(ref)
@@ -44,7 +70,7 @@ def main():
             print("MISMATCH seed", seed, e, flush=True)
         s.close()
         o.close()
-    print(f"GPU fuzz seeds {first}..{last} crowd={crowd}: {bad} mismatches, worst L-inf on mean radiance {worst:.3e}, launch shapes {shapes}", flush=True)
+    print(f"GPU fuzz seeds {first}..{last} crowd={crowd} ident={ident}: {bad} mismatches, worst L-inf on mean radiance {worst:.3e}, launch shapes {shapes}", flush=True)
     return 1 if bad else 0
 
 
