@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 from conftest import make_holder  # noqa: E402
-from test_fuzz_scenes import random_scene, crowd_scene, _check  # noqa: E402
+from test_fuzz_scenes import random_scene, crowd_scene, ident_scene, _check  # noqa: E402
 
 
 def main():
@@ -21,27 +21,6 @@ def main():
     crowd = len(sys.argv) > 3 and sys.argv[3] == "crowd"
     ident = len(sys.argv) > 3 and sys.argv[3] == "ident"
 
-    def ident_scene(seed):
-        d = random_scene(seed)
-        rng = np.random.default_rng(seed + 4242)
-        keep = []
-        for o in d["scene"]["renderer"]:
-            if o["type"] in ("mesh", "triangle"):
-                continue                                      # (plain kernels only: planes, spheres, boxes)
-            o.pop("dir", None)
-            if "inst" in o:
-                o["inst"] = [[[float(round(c * 2) / 2) for c in i[0]], [0, 0, -1, 0]] for i in o["inst"]]
-            elif "pos" in o:
-                o["pos"] = [float(round(c * 2) / 2) for c in o["pos"]]
-            o.get("mat", {}).pop("tex", None)
-            for k in ("rmap", "mmap", "gmap", "omap", "emap"):
-                o.get("mat", {}).pop(k, None)
-            keep.append(o)
-        d["scene"]["renderer"] = keep or [{"type": "sphere", "r": 0.5}]
-        if rng.random() < 0.5:                                # camera on the lattice, looking straight down +y, pinhole
-            cam = d["frame"]["cam"]
-            cam["pos"] = [0.0, -2.0, 0.0]; cam["dir"] = [0, 0, 1, 0]; cam["aprt"] = 0.0
-        return d
     oracle_mod = importlib.import_module("oracle.oracle")
     bad = 0
     worst = 0.0

@@ -68,6 +68,31 @@ def crowd_scene(seed):
     return d
 
 
+def ident_scene(seed):
+    """random_scene with every instance untransformed, on a half-unit lattice, no maps; half of the cameras are axis-aligned
+    pinholes on a lattice point: rays and shifted origins with zero components everywhere (the F_IDENT kernels, mrt_trace.h)."""
+    d = random_scene(seed)
+    rng = np.random.default_rng(seed + 4242)
+    keep = []
+    for o in d["scene"]["renderer"]:
+        if o["type"] in ("mesh", "triangle"):
+            continue                                      # (plain kernels only: planes, spheres, boxes)
+        o.pop("dir", None)
+        if "inst" in o:
+            o["inst"] = [[[float(round(c * 2) / 2) for c in i[0]], [0, 0, -1, 0]] for i in o["inst"]]
+        elif "pos" in o:
+            o["pos"] = [float(round(c * 2) / 2) for c in o["pos"]]
+        o.get("mat", {}).pop("tex", None)
+        for k in ("rmap", "mmap", "gmap", "omap", "emap"):
+            o.get("mat", {}).pop(k, None)
+        keep.append(o)
+    d["scene"]["renderer"] = keep or [{"type": "sphere", "r": 0.5}]
+    if rng.random() < 0.5:                                # camera on the lattice, looking straight down +y, pinhole
+        cam = d["frame"]["cam"]
+        cam["pos"] = [0.0, -2.0, 0.0]; cam["dir"] = [0, 0, 1, 0]; cam["aprt"] = 0.0
+    return d
+
+
 def _check(got, ref, spp):
     assert (np.isnan(got) == np.isnan(ref)).all()
     fin = np.isfinite(ref)
@@ -76,9 +101,9 @@ def _check(got, ref, spp):
         assert np.abs(got[fin] - ref[fin]).max() / spp <= 1e-4 * scale
 
 
-@pytest.mark.parametrize("seed", list(range(40)) + [1000 + k for k in range(8)])
+@pytest.mark.parametrize("seed", list(range(40)) + [1000 + k for k in range(8)] + [2000 + k for k in range(4)])
 def test_fuzz_kernel_headers_on_x86(seed, oracle_mod, emu_mod):
-    render, h = make_holder(crowd_scene(seed - 1000) if seed >= 1000 else random_scene(seed))
+    render, h = make_holder(ident_scene(seed - 2000) if seed >= 2000 else (crowd_scene(seed - 1000) if seed >= 1000 else random_scene(seed)))
     spp = render.rt.sample
     o = oracle_mod.Oracle(h, seed=seed)
     o.execute(spp)
@@ -91,10 +116,10 @@ def test_fuzz_kernel_headers_on_x86(seed, oracle_mod, emu_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(0, 40, 3)) + [1000, 1001, 1002, 1004])
+@pytest.mark.parametrize("seed", list(range(0, 40, 3)) + [1000, 1001, 1002, 1004] + [2000 + k for k in range(10)])
 def test_fuzz_gpu(seed, oracle_mod):
     from micro_raytracer_amd import Sampler
-    render, h = make_holder(crowd_scene(seed - 1000) if seed >= 1000 else random_scene(seed))
+    render, h = make_holder(ident_scene(seed - 2000) if seed >= 2000 else (crowd_scene(seed - 1000) if seed >= 1000 else random_scene(seed)))
     spp = render.rt.sample
     o = oracle_mod.Oracle(h, seed=seed)
     o.execute(spp)
