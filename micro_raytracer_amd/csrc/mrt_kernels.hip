@@ -339,7 +339,9 @@ u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
     if (features & F_BVH) {
         if (!scene_in_lds) return big | F_BVH;
         const u32 pick = (need & (F_BOX | F_TRI | F_MAPS)) == 0 ? (need & F_LIGHTS) : big;
-        return pick | F_BVH | nostash | cold;
+        // sphere / plane crowds whose instances are all untransformed (the reference's Instance.json): F_IDENT builds
+        const u32 ident = ((features & F_IDENT) && pick != big && !nostash && !cold && block_threads != 64u) ? (u32)F_IDENT : 0u;
+        return pick | F_BVH | nostash | cold | ident;
     }
     if (!scene_in_lds) return big;
     if (cold) return big | cold;
@@ -356,6 +358,7 @@ u32 pt_instantiation(u32 block_threads, bool scene_in_lds, u32 features)
 #define MRT_BVH4(T, X) MRT_CASE(T, F_BVH | (X)) MRT_CASE(T, F_LIGHTS | F_BVH | (X)) MRT_CASE(T, (F_ALL & ~F_TRI) | F_BVH | (X)) MRT_CASE(T, F_ALL | F_BVH | (X))
 #define MRT_BIG2(T, X) MRT_CASE(T, (F_ALL & ~F_TRI) | (X)) MRT_CASE(T, F_ALL | (X))
 #define MRT_IDENT4(T) MRT_CASE(T, F_IDENT) MRT_CASE(T, F_IDENT | F_BOX) MRT_CASE(T, F_IDENT | F_LIGHTS) MRT_CASE(T, F_IDENT | F_BOX | F_LIGHTS)
+#define MRT_IDENT_BVH2(T) MRT_CASE(T, F_IDENT | F_BVH) MRT_CASE(T, F_IDENT | F_LIGHTS | F_BVH)
 #define MRT_DEEP2(T) MRT_CASE(T, F_ALL | F_COLD | F_DEEP) MRT_CASE(T, F_ALL | F_BVH | F_COLD | F_DEEP)
 
 hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 features, hipStream_t stream)
@@ -375,11 +378,11 @@ hipError_t launch_pt(const Params &P, u32 block_threads, bool scene_in_lds, u32 
     } else if (block_threads == 64u) {
         switch (inst) { MRT_PLAIN16(64) MRT_BVH4(64, 0u) default: break; }
     } else if (block_threads == 256u) {
-        switch (inst) { MRT_PLAIN16(256) MRT_IDENT4(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256) default: break; }
+        switch (inst) { MRT_PLAIN16(256) MRT_IDENT4(256) MRT_BVH4(256, 0u) MRT_IDENT_BVH2(256) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256) default: break; }
     } else if (block_threads == 512u) {
-        switch (inst) { MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512) default: break; }
+        switch (inst) { MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_IDENT_BVH2(512) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512) default: break; }
     } else if (block_threads == 1024u) {
-        switch (inst) { MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH)
+        switch (inst) { MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_IDENT_BVH2(1024) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH)
                         MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) MRT_DEEP2(1024) default: break; }
     }
     return hipErrorInvalidConfiguration;
@@ -399,9 +402,9 @@ hipError_t configure_pt(size_t max_lds_bytes)
     hipError_t e;
 #define MRT_CASE(T, F) if ((e = set_lds_attr<T, (F)>(b)) != hipSuccess) return e;
     MRT_PLAIN16(64) MRT_BVH4(64, 0u)
-    MRT_PLAIN16(256) MRT_IDENT4(256) MRT_BVH4(256, 0u) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256)
-    MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512)
-    MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) MRT_DEEP2(1024)
+    MRT_PLAIN16(256) MRT_IDENT4(256) MRT_BVH4(256, 0u) MRT_IDENT_BVH2(256) MRT_BIG2(256, F_COLD) MRT_BVH4(256, F_COLD) MRT_DEEP2(256)
+    MRT_BIG2(512, 0u) MRT_BVH4(512, 0u) MRT_IDENT_BVH2(512) MRT_BIG2(512, F_COLD) MRT_BVH4(512, F_COLD) MRT_DEEP2(512)
+    MRT_BIG2(1024, 0u) MRT_BVH4(1024, 0u) MRT_IDENT_BVH2(1024) MRT_BIG2(1024, F_NOSTASH) MRT_BVH4(1024, F_NOSTASH) MRT_BIG2(1024, F_COLD) MRT_BVH4(1024, F_COLD) MRT_DEEP2(1024)
 #undef MRT_CASE
     return hipSuccess;
 }

@@ -1025,8 +1025,8 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray_, Hit &best)
         // misses its box grown by the ray's margin (below): tens to hundreds of times the rounding error of
         // the exact tests at the ray's distance from the farthest instance.  Rays that are not finite or not unit length
         // are not culled at all.
-        const bool cull = cull_ok(ray.o, ray.dd);
-        const CullRay R = cull_ray(ray.o, ray.d);
+        const bool cull = cull_ok(ray_.o, ray_.dd);         // (the ray as given: F_IDENT's ray_i only serves the exact tests)
+        const CullRay R = cull_ray(ray_.o, ray_.d);
         const float *N0 = F + P.off_bvh;
         u32 node = P.n_bvh_nodes ? 0u : BVH_END;
         // ONE margin per ray, from the root box (node 0): k x its extent seen from the origin + ksq x that extent squared (spheres)
@@ -1037,7 +1037,7 @@ MRT_HD bool trace(const Scn &S, const RayPre &ray_, Hit &best)
             const F4 ra = ld4(N0, 0), rb = ld4(N0, 4);
             const V3 r = sub(v3(ra.x, ra.y, ra.z), R.o);
             const float ext = fmax_(fmax_(fabs_(r.x) + ra.w, fabs_(r.y) + rb.x), fabs_(r.z) + rb.y);
-            const float obig = fmax_(fmax_(fabs_(ray.o.x), fabs_(ray.o.y)), fabs_(ray.o.z));
+            const float obig = fmax_(fmax_(fabs_(ray_.o.x), fabs_(ray_.o.y)), fabs_(ray_.o.z));
             // (spheres: sqrt(r^2 + 2 eps' D^2) - r <= min(eps' D^2 / r, sqrt(2 eps') D) -- the square law up to D / r = 1000, 4e-3 D beyond)
             const float ksq = fmin_(P.inst_ksq * ext, 4e-3f) * MRT_MARGIN_SCALE;
             mg = fma_fast(P.inst_k * MRT_MARGIN_SCALE + ksq, ext, fma_fast(P.inst_kpos * MRT_MARGIN_SCALE, obig + obig + ext, 1e-6f * MRT_MARGIN_SCALE));

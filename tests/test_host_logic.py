@@ -463,7 +463,7 @@ def test_launch_plan_staging_levels_and_shapes(monkeypatch):
         assert 300 < p["tbvh_hot_nodes"] < p["tbvh_nodes"] and LDS - 4096 < p["lds_bytes"] <= LDS and p["walk_cap"] == 16
     # 1000 instances, no texels: nothing to leave out, one copy for a 1024-thread workgroup
     p = plan(scenes.instance_grid())
-    assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("all", 1024, 8 | 16), p
+    assert (p["staging"], p["block_threads"], p["kernel_features"]) == ("all", 1024, 8 | 16 | 256), p      # (256: all untransformed)
     # the knobs of the tests
     monkeypatch.setenv("MRT_SCENE_IN_L2", "1")
     p = plan(scenes.mesh_scene())
