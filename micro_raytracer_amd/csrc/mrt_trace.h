@@ -142,6 +142,23 @@ MRT_HD void sched_fence()
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+// Values the compiler must take as they are (device): a word it would otherwise trace back to a float load and compare by
+// class (a mask constant re-loaded every loop trip), a loop constant it would fold to a literal that VOP3 cannot encode (a
+// v_mov per trip).  Empty asm, no instruction.
+MRT_HD u32 opaque_v(u32 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+MRT_HD u32 opaque_s(u32 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
 // index of the lowest set bit of a non-zero word (v_ffbl_b32)
 MRT_HD u32 lowest_bit(u32 x) { return (u32)__builtin_ctz(x | 0x80000000u); }
 
@@ -740,7 +757,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
             WalkMem q(S);
             for (;;) {
                 u32 qo = 0u;                                            // byte offset of the next free queue entry
-                const u32 q_pitch = q.pitch(), q_full = kQ * q_pitch;
+                const u32 q_pitch = opaque_s(q.pitch()), q_full = kQ * q_pitch;     // (a scalar register, not a literal to re-load per step)
                 u32 probe_steps = 0; (void)probe_steps;
                 bool walking = node != BVH_END;
                 while (walking) {
@@ -748,7 +765,7 @@ MRT_HD bool mesh_isect(const Scn &S, u32 mesh, V3 ro, V3 rd, float dd, V3 m, V3 
                     const F4 na = ld4(B0, node * BVH_WORDS), nb = ld4(B0, node * BVH_WORDS + 4);
                     MRT_COUNT(CT_TBVH_NODE);
                     const u32 skip = f2u(nb.z);
-                    const u32 leaf = f2u(nb.w), child = node + 1u;
+                    const u32 leaf = opaque_v(f2u(nb.w)), child = node + 1u;        // (an integer to the compiler: `!= 0` stays v_cmp_ne_u32)
                     const float px = fma_fast(na.x, R.inv.x, -oinv.x), py = fma_fast(na.y, R.inv.y, -oinv.y), pz = fma_fast(na.z, R.inv.z, -oinv.z);
                     const float qx = fma_fast(na.w, R.ainv.x, qm.x), qy = fma_fast(nb.x, R.ainv.y, qm.y), qz = fma_fast(nb.y, R.ainv.z, qm.z);
                     const float tn = fmax_(fmax_(px - qx, py - qy), pz - qz);
